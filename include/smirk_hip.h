@@ -1,0 +1,180 @@
+/* smirk_hip.h — C ABI of libsmirk_hip.so: the MI355X (gfx950) implementation of SMIRK's per-frame hot path
+ *   SmirkEncoder -> FLAME -> Renderer -> SmirkGenerator   (reference: demo.py:107-112,167-169; smirk_trainer.py:37-48,94)
+ *
+ * The reference has no FFI layer: its boundary is four Python nn.Modules.  Each entry point below is
+ * what a binding for that module's forward() would call; the file:line it replaces is cited on every declaration.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer to contiguous memory, fp32 unless the name says otherwise; the caller owns all
+ *     buffers (inputs, outputs, workspace) — the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream) and the call returns at once;
+ *   - return value: 0 = SMIRK_OK, negative = error (smirk_strerror); nothing throws, nothing prints;
+ *   - image tensors at the boundary are NCHW like the reference; internal activations are NHWC fp32;
+ *   - results: raster indices bit-exact vs the reference algorithm, everything else within the fp32 tolerances
+ *     stated in tests/ (DESIGN.md §Numerics).
+ */
+#ifndef SMIRK_HIP_H
+#define SMIRK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMIRK_OK 0
+#define SMIRK_ERR_BAD_ARG (-1)
+#define SMIRK_ERR_WORKSPACE (-2)
+#define SMIRK_ERR_LAUNCH (-3)
+#define SMIRK_ERR_UNSUPPORTED (-4)
+
+const char* smirk_strerror(int code);
+/* ABI version of this header (bumped on any signature change). */
+int smirk_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * FLAME  — replaces FLAME.forward (src/FLAME/FLAME.py:232-315) incl. lbs() (src/FLAME/lbs.py:140-227),
+ *          batch_rodrigues (:274-305), batch_rigid_transform (:321-378), the dynamic-landmark LUT
+ *          (FLAME.py:117-159) and vertices2landmarks (lbs.py:101-137).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define SMIRK_FLAME_KCHUNK 32 /* K padding granule of the packed blendshape basis */
+
+typedef struct SmirkFlameModel {
+    int32_t V;        /* 5023 vertices                                   (FLAME.py:61 v_template)            */
+    int32_t VP;       /* V rounded up to 32 (row count of `dirs` planes)                                         */
+    int32_t F;        /* 9976 faces                                      (FLAME.py:58 faces_tensor)          */
+    int32_t n_shape;  /* 300                                             (FLAME.py:50)                       */
+    int32_t n_exp;    /* 50                                                                                  */
+    int32_t KP;       /* (n_shape+n_exp+36) rounded up to SMIRK_FLAME_KCHUNK                                 */
+    int32_t n_static; /* 51 static FAN landmarks                         (FLAME.py:97-98)                    */
+    int32_t n_dyn;    /* 17 dynamic contour landmarks per LUT row        (FLAME.py:99-100)                   */
+    int32_t n_lut;    /* 79 LUT rows                                                                         */
+    int32_t n_full;   /* 68                                              (FLAME.py:101-102)                  */
+    int32_t n_mp;     /* 105                                             (FLAME.py:112-113)                  */
+    int32_t _pad;
+    const float* dirs;        /* [3][VP][KP]  packed basis: k<n_shape+n_exp -> shapedirs[v][c][k] (FLAME.py:67-69),
+                                 next 36 -> posedirs[k][3v+c] (FLAME.py:71-73), rest 0; k contiguous            */
+    const float* v_template;  /* [V][3]                                                                        */
+    const float* lbs_weights; /* [V][5]                                (FLAME.py:78)                         */
+    const float* jdirs;       /* [15][n_shape+n_exp]  J_regressor . shapedirs, joint-major (j*3+c)             */
+    const float* jtemplate;   /* [15]                 J_regressor . v_template                               */
+    const float* l_eyelid;    /* [V][3]                                (FLAME.py:81)                         */
+    const float* r_eyelid;    /* [V][3]                                (FLAME.py:82)                         */
+    const int32_t* faces;     /* [F][3]                                                                       */
+    const int32_t* static_faces;  const float* static_bary;  /* [n_static], [n_static][3]                     */
+    const int32_t* dyn_faces;     const float* dyn_bary;     /* [n_lut][n_dyn], [n_lut][n_dyn][3]             */
+    const int32_t* full_faces;    const float* full_bary;    /* [n_full], [n_full][3]                         */
+    const int32_t* mp_faces;      const float* mp_bary;      /* [n_mp], [n_mp][3]                             */
+} SmirkFlameModel;
+
+/* bytes of scratch smirk_flame_forward needs for batch B (coef[B][KP] + joint transforms[B][60] + lut[B]) */
+size_t smirk_flame_workspace_bytes(const SmirkFlameModel* m /*host struct*/, int B);
+
+/* Inputs [B,*]; `neck`, `eye`, `eyelid` may be NULL (=> zeros / no eyelid term, FLAME.py:267-271,284).
+ * ns_in / ne_in: number of shape / expression coefficients actually supplied (right-padded with zeros, FLAME.py:244-248).
+ * Outputs: verts[B][V][3], lmk_fan[B][n_dyn+n_static][3], lmk_fan3d[B][n_full][3], lmk_mp[B][n_mp][3];
+ * lut_idx_out (nullable) [B] int32 = the dynamic-contour LUT row chosen per face (for parity tests).
+ * `m` is a HOST struct whose members are device pointers. */
+int smirk_flame_forward(const SmirkFlameModel* m, int B,
+                        const float* shape, int ns_in, const float* exp, int ne_in,
+                        const float* global_pose /*[B,3]*/, const float* neck /*[B,3]*/, const float* jaw /*[B,3]*/,
+                        const float* eye /*[B,6]*/, const float* eyelid /*[B,2]*/,
+                        float* verts, float* lmk_fan, float* lmk_fan3d, float* lmk_mp, int32_t* lut_idx_out,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* Barycentric landmark gather on its own — replaces vertices2landmarks (lbs.py:101-137) as used by
+ * utils/masking.py:170 with per-face index/bary tensors.  faces_idx[B][L] int32, bary[B][L][3] -> out[B][L][3]. */
+int smirk_vertices2landmarks(const float* verts, int B, int V, const int32_t* faces /*[F][3]*/,
+                             const int32_t* faces_idx, const float* bary, int L, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Renderer — replaces Renderer.forward/render/rasterize/add_directionlight (src/renderer/renderer.py:100-207,239-250),
+ *            vertex_normals/face_vertices/batch_orth_proj (src/renderer/util.py:10-78) and the pytorch3d call
+ *            rasterize_meshes(image_size=224, blur_radius=0, faces_per_pixel=1) (renderer.py:185-193).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct SmirkRenderMesh {
+    int32_t V;        /* vertices of the full mesh (5023)                                                       */
+    int32_t Vf;       /* kept (face-region) vertices, 1787             (renderer.py:68-73)                      */
+    int32_t Ff;       /* faces of the kept sub-mesh, 3408              (renderer.py:11-47)                      */
+    int32_t nnz;      /* 3*Ff corner contributions of the normal CSR                                            */
+    const int32_t* keep;      /* [Vf]   full-mesh vertex id of each kept vertex (sorted)                        */
+    const int32_t* faces;     /* [Ff][3] sub-mesh faces, indices into the kept vertices                         */
+    const int32_t* nrm_ptr;   /* [Vf+1] CSR row pointers: corner contributions per vertex, in the reference's
+                                 index_add_ order (util.py:52-57: corner1 pass, corner2 pass, corner0 pass)      */
+    const int32_t* nrm_face;  /* [nnz]  face id of each contribution                                            */
+    const int32_t* nrm_corner;/* [nnz]  which corner (0,1,2) of that face the vertex is                         */
+} SmirkRenderMesh;
+
+size_t smirk_render_workspace_bytes(const SmirkRenderMesh* mesh /*host struct*/, int B, int H, int W);
+
+/* verts[B][V][3], cam[B][3]=(s,tx,ty) -> transformed[B][V][3] (renderer.py:101-102), img[B][3][H][W] (NCHW, background
+ * exactly 0.0).  Optional outputs (nullable): pix_to_face[B][H][W] int64 packed index b*Ff+f or -1 (renderer.py:185),
+ * bary[B][H][W][3] (-1 background), zbuf[B][H][W] (-1 background), normals[B][Vf][3].  H, W <= 1024; H == W. */
+int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, int W,
+                         const float* verts, const float* cam,
+                         float* transformed, float* img,
+                         int64_t* pix_to_face, float* bary, float* zbuf, float* normals,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* Landmark projection (renderer.py:104-108): lmk[B][L][3], cam[B][3] -> out[B][L][2]. */
+int smirk_project_landmarks(const float* lmk, const float* cam, int B, int L, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convolution building blocks (fp32 MFMA implicit GEMM, NHWC) — replace the cuDNN/ATen kernels the reference reaches
+ * through nn.Conv2d / nn.ConvTranspose2d / nn.BatchNorm2d(eval) / ReLU / MaxPool2d / ReflectionPad2d
+ * (src/smirk_generator.py:13-44,88-178) and timm's conv/bn/act stacks (src/smirk_encoder.py:7-12).
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { SMIRK_PAD_ZERO = 0, SMIRK_PAD_REFLECT = 1 };
+enum { SMIRK_ACT_NONE = 0, SMIRK_ACT_RELU = 1 };
+enum { SMIRK_OUT_NHWC = 0, SMIRK_OUT_CONVT2X2 = 1 };
+
+typedef struct SmirkConvDesc {
+    int32_t B, H, W;        /* input spatial size                                                               */
+    int32_t C0, C1;         /* channels of source 0 and (optional, concat along C) source 1; both % 4 == 0        */
+    int32_t Cout;           /* output channels (for CONVT2X2: channels per output pixel)                        */
+    int32_t KH, KW;         /* 3x3 or 1x1                                                                       */
+    int32_t stride;         /* 1 (2 is accepted for 1x1 / 3x3 with the pads below)                              */
+    int32_t pad_t, pad_l;   /* leading pads; trailing pads follow from Ho, Wo                                    */
+    int32_t Ho, Wo;         /* output spatial size (CONVT2X2: the GEMM grid = input grid, output is 2H x 2W)    */
+    int32_t pad_mode;       /* SMIRK_PAD_*                                                                      */
+    int32_t act;            /* SMIRK_ACT_*  (applied after scale/shift and residual add)                         */
+    int32_t out_mode;       /* SMIRK_OUT_*                                                                      */
+} SmirkConvDesc;
+
+/* out = act( (conv(cat(in0,in1), w)) * scale[n] + shift[n] + residual ).
+ * w: [N][K] with K = KH*KW*(C0+C1) ordered (ky,kx,c) and N = Cout (CONVT2X2: N = 4*Cout ordered (dy,dx,co), K = C0);
+ * scale/shift: [Cout] (nullable => 1 / 0); residual (nullable): NHWC like out.  in1 may be NULL when C1 == 0. */
+int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* in1, const float* w,
+                         const float* scale, const float* shift, const float* residual, float* out, void* stream);
+
+/* 2x2/2 max pool, NHWC, C % 4 == 0 (smirk_generator.py:13-19). */
+int smirk_maxpool2x2_nhwc(const float* in, float* out, int B, int H, int W, int C, void* stream);
+/* NCHW [B,Cin,H,W] -> NHWC [B,H,W,Cpad] with zero-filled channels Cin..Cpad-1 (generator input pack). */
+int smirk_nchw_to_nhwc_pad(const float* in, float* out, int B, int Cin, int H, int W, int Cpad, void* stream);
+/* Same, but the 6 input channels come from two NCHW 3-channel tensors (rendered, masked) => cat fused (smirk_trainer.py:94). */
+int smirk_pack_generator_input(const float* rendered, const float* masked, float* out, int B, int H, int W, void* stream);
+/* final 1x1 conv (C -> Cout<=4) + bias + sigmoid, NHWC in -> NCHW out (smirk_generator.py:47-49,76). */
+int smirk_conv1x1_sigmoid_nchw(const float* in, const float* w /*[Cout][C]*/, const float* bias, float* out,
+                               int B, int H, int W, int C, int Cout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Encoder-specific ops (timm tf_mobilenetv3_*_minimal_100 stacks; src/smirk_encoder.py:34-45,66-73,95-110).
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* stem: 3x3 stride-2 TF-'same' conv 3->Cout(16) on NCHW input + BN(scale,shift) + ReLU -> NHWC [B,H/2,W/2,Cout]. */
+int smirk_stem_conv_s2(const float* img_nchw, const float* w /*[Cout][27] (ky,kx,c)*/, const float* scale,
+                       const float* shift, float* out, int B, int H, int W, int Cout, void* stream);
+/* depthwise 3x3, stride 1 (pad 1) or 2 (TF-'same': pad 0 top/left, 1 bottom/right for even H), + scale/shift + ReLU. NHWC. */
+int smirk_dwconv3x3(const float* in, const float* w /*[9][C]*/, const float* scale, const float* shift, float* out,
+                    int B, int H, int W, int C, int stride, int relu, void* stream);
+/* global average pool over HW then Linear: feat[B][HW][C] -> out[B][N] = mean_hw(feat) . Wt[N][C] + bias. */
+int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C, int N,
+                     void* stream);
+/* ExpressionEncoder output clamps (smirk_encoder.py:104-108), in place on params[B][n_exp+5]:
+ * [n_exp, n_exp+2) clamp(0,1); [n_exp+2] relu; [n_exp+3, n_exp+5) clamp(-.2,.2). */
+int smirk_expression_clamps(float* params, int B, int n_exp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMIRK_HIP_H */

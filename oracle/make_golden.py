@@ -1,0 +1,80 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Regenerates tests/golden/*.npz by running the REAL reference classes (imported from /root/reference through
+oracle/sandbox.py) on seeded synthetic inputs.  Runs only in the build container; the fixtures travel to the GPU box.
+
+    python -m oracle.make_golden            # writes tests/golden/{assets_bundle,flame,render,generator,encoder}_golden.npz
+
+What each fixture pins
+  flame_golden      reference FLAME.forward (FLAME.py:232-315) outputs, B=4                      -> fully pinned
+  generator_golden  reference SmirkGenerator(6,3,32,5).eval() (smirk_generator.py:51-86), B=1    -> fully pinned
+  render_golden     reference Renderer.forward (renderer.py:100-207) on top of oracle/raster_ref.c -> glue pinned,
+                    rasteriser itself PARITY UNPINNED (pytorch3d not on disk)
+  encoder_golden    reference SmirkEncoder.forward heads/clamps (smirk_encoder.py:34-133) on top of
+                    oracle/mobilenet_ref.py backbones                                            -> heads pinned,
+                    backbone PARITY UNPINNED (timm not on disk)
+"""
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+from . import assets as A
+from . import generator_ref as G
+from . import mobilenet_ref as M
+from . import sandbox as S
+
+GOLD = os.path.join(A.REPO, "tests", "golden")
+
+
+def main():
+    assert S.available(), "needs /root/reference"
+    A.build_bundle_from_reference(S.REF_ROOT)
+    bundle = A.load_bundle()
+    d = tempfile.mkdtemp(prefix="smirk_sandbox_")
+    A.write_sandbox(d, bundle)
+    with S.reference(d) as ref, torch.no_grad():
+        # ---- FLAME ------------------------------------------------------------------------------
+        p = A.synth_flame_params(4, seed=11)
+        fl = ref.FLAME()
+        out = fl.forward({k: torch.from_numpy(v) for k, v in p.items()})
+        np.savez_compressed(os.path.join(GOLD, "flame_golden.npz"), seed=11,
+                            **{"in_" + k: v for k, v in p.items()},
+                            **{k: v.numpy() for k, v in out.items()})
+        # ---- Renderer ---------------------------------------------------------------------------
+        cam = A.synth_cam(4, seed=11)
+        rn = ref.Renderer()
+        ro = rn.forward(out["vertices"][:2], torch.from_numpy(cam[:2]), landmarks_fan=out["landmarks_fan"][:2],
+                        landmarks_mp=out["landmarks_mp"][:2])
+        img = ro["rendered_img"].numpy()
+        assert np.array_equal(img[:, 0], img[:, 1]) and np.array_equal(img[:, 0], img[:, 2])
+        np.savez_compressed(os.path.join(GOLD, "render_golden.npz"), cam=cam[:2],
+                            rendered_ch0=img[:, 0], transformed_vertices=ro["transformed_vertices"].numpy(),
+                            landmarks_fan=ro["landmarks_fan"].numpy(), landmarks_mp=ro["landmarks_mp"].numpy())
+        # ---- Generator --------------------------------------------------------------------------
+        sd = G.synth_state_dict()
+        g = ref.SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+        g.load_state_dict(sd)
+        g.eval()
+        x = A.synth_generator_input(1, seed=21)
+        y = g(x).numpy()
+        np.savez_compressed(os.path.join(GOLD, "generator_golden.npz"), seed=21, y_sub4=y[:, :, ::4, ::4],
+                            y_sum=np.float64(y.astype(np.float64).sum()), y_sumsq=np.float64((y.astype(np.float64) ** 2).sum()),
+                            w_checksum=np.float64(sum(float(v.double().abs().sum()) for v in sd.values())))
+        # ---- Encoder ----------------------------------------------------------------------------
+        esd = M.synth_encoder_state_dict()
+        e = ref.SmirkEncoder()
+        e.load_state_dict(esd)
+        e.eval()
+        img_in = A.synth_images(2, seed=31)
+        eo = e(img_in)
+        np.savez_compressed(os.path.join(GOLD, "encoder_golden.npz"), seed=31,
+                            w_checksum=np.float64(sum(float(v.double().abs().sum()) for v in esd.values())),
+                            **{k: v.numpy() for k, v in eo.items()})
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

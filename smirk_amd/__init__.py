@@ -1,0 +1,11 @@
+"""smirk_amd — MI355X (gfx950) implementation of SMIRK's per-frame hot path behind the reference's own class names.
+
+    from smirk_amd import SmirkEncoder, FLAME, Renderer, SmirkGenerator      # drop-in for src.smirk_encoder / src.FLAME.FLAME /
+                                                                              # src.renderer.renderer / src.smirk_generator
+All arithmetic runs in hand-written HIP kernels (smirk_amd/csrc/*.hip -> lib/libsmirk_hip.so, C ABI in include/smirk_hip.h).
+There is no CPU or eager-PyTorch fallback: calls raise if the library is not built or tensors are not on the GPU.
+"""
+from ._lib import SmirkHipError, lib  # noqa: F401
+from .FLAME import FLAME  # noqa: F401
+
+__all__ = ["FLAME", "SmirkHipError", "lib"]

@@ -1,0 +1,128 @@
+"""ctypes binding of libsmirk_hip.so (C ABI declared in include/smirk_hip.h).
+
+There is NO fallback: if the shared object is missing or a tensor is not on the HIP device the call raises.
+torch is used for device memory and streams only; every pointer handed to the library is `tensor.data_ptr()`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
+ABI_VERSION = 1
+
+_p = C.c_void_p
+_i = C.c_int
+_sz = C.c_size_t
+
+
+class SmirkFlameModel(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("V", "VP", "F", "n_shape", "n_exp", "KP", "n_static", "n_dyn", "n_lut",
+                                         "n_full", "n_mp", "_pad")] + \
+               [(n, _p) for n in ("dirs", "v_template", "lbs_weights", "jdirs", "jtemplate", "l_eyelid", "r_eyelid",
+                                  "faces", "static_faces", "static_bary", "dyn_faces", "dyn_bary", "full_faces",
+                                  "full_bary", "mp_faces", "mp_bary")]
+
+
+class SmirkRenderMesh(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("V", "Vf", "Ff", "nnz")] + \
+               [(n, _p) for n in ("keep", "faces", "nrm_ptr", "nrm_face", "nrm_corner")]
+
+
+class SmirkConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C0", "C1", "Cout", "KH", "KW", "stride", "pad_t", "pad_l",
+                                         "Ho", "Wo", "pad_mode", "act", "out_mode")]
+
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+OUT_NHWC, OUT_CONVT2X2 = 0, 1
+
+_SIGS = {
+    "smirk_strerror": (C.c_char_p, [_i]),
+    "smirk_abi_version": (_i, []),
+    "smirk_flame_workspace_bytes": (_sz, [C.POINTER(SmirkFlameModel), _i]),
+    "smirk_flame_forward": (_i, [C.POINTER(SmirkFlameModel), _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                 _p, _sz, _p]),
+    "smirk_vertices2landmarks": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "smirk_render_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
+    "smirk_render_forward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "smirk_project_landmarks": (_i, [_p, _p, _i, _i, _p, _p]),
+    "smirk_conv_igemm_f32": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "smirk_maxpool2x2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "smirk_nchw_to_nhwc_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "smirk_pack_generator_input": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "smirk_conv1x1_sigmoid_nchw": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smirk_stem_conv_s2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_dwconv3x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smirk_gap_linear": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_expression_clamps": (_i, [_p, _i, _i, _p]),
+}
+EXPORTS = tuple(_SIGS)
+
+_LIB = None
+
+
+class SmirkHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SmirkHipError(f"{LIB_PATH} not found: build it with `python -m smirk_amd.build` "
+                                "(smirk_amd has no CPU / eager fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)           # AttributeError => header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        if L.smirk_abi_version() != ABI_VERSION:
+            raise SmirkHipError("libsmirk_hip.so ABI version mismatch; rebuild")
+        _LIB = L
+    return _LIB
+
+
+def check(code):
+    if code != 0:
+        raise SmirkHipError(f"libsmirk_hip: {lib().smirk_strerror(code).decode()} ({code})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32, allow_none=False):
+    """Device pointer of a contiguous tensor of the expected dtype that lives on the HIP device."""
+    if t is None:
+        if allow_none:
+            return None
+        raise SmirkHipError("missing tensor argument")
+    if not t.is_cuda:
+        raise SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise SmirkHipError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise SmirkHipError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def as_f32c(t):
+    """float32 contiguous view/copy (device-side plumbing only)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Workspace:
+    """Grow-only byte scratch buffer owned by a module (the library never allocates)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self.buf

@@ -1,0 +1,340 @@
+// FLAME layer for MI355X (gfx950): three launches per batch, no intermediate larger than [B][KP].
+//
+//   flame_prologue   one 64-lane wave per face: assemble the coefficient row [betas | pose_feature | 0],
+//                    regress the 5 joints from the precomputed J_regressor.shapedirs matrix (wave reductions),
+//                    Rodrigues + kinematic chain -> 5 skinning transforms (3x4 each), dynamic-contour LUT row.
+//                    (FLAME.py:117-159,274-275; lbs.py:188-210,274-378)
+//   flame_blend_skin fp32 MFMA GEMM  coef[B][KP] x dirs[3][VP][KP]^T  (v_mfma_f32_32x32x2_f32, exact f32 FMA chain),
+//                    128 faces x 32 vertices x {x,y,z} per workgroup, LDS-staged K chunks; the epilogue adds the template,
+//                    blends the joint transforms per vertex (never materialising T[B][V][4][4] — 165 MB at B=512 in the
+//                    reference), applies them and adds the eyelid blendshapes.  (lbs.py:184,197-225; FLAME.py:284-286)
+//   flame_landmarks  barycentric gather of the 68 + 68 + 105 landmarks.  (FLAME.py:288-308; lbs.py:101-137)
+//
+// Bound: MFMA fp32 (2*B*3*VP*KP flop) at large B; launch latency at small B.  HBM traffic per launch: the 23.4 MB basis
+// once (L2/MALL-resident across M-tiles) + 60 KB of vertices per face.
+#include "common.h"
+
+#define FL_BM 128          // faces per workgroup (4 waves x 32)
+#define FL_BV 32           // vertices per workgroup
+#define FL_BK SMIRK_FLAME_KCHUNK
+#define FL_LDS_STRIDE (FL_BK + 4)   // 36 floats: ds_read_b128 of 16 rows hits 16 distinct 16-B slots
+
+struct FlameDev {           // by-value kernel argument: the device pointers of SmirkFlameModel
+    int V, VP, F, n_shape, n_exp, KP;
+    int n_static, n_dyn, n_lut, n_full, n_mp;
+    const float *dirs, *v_template, *lbs_weights, *jdirs, *jtemplate, *l_eyelid, *r_eyelid;
+    const int32_t* faces;
+    const int32_t *static_faces, *dyn_faces, *full_faces, *mp_faces;
+    const float *static_bary, *dyn_bary, *full_bary, *mp_bary;
+};
+
+// R = I + sin(t) K + (1 - cos(t)) K.K with t = |r + 1e-8| (eps added to the vector) and K from r / t   (lbs.py:274-305)
+__device__ inline void rodrigues(const float* r, float R[9]) {
+    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
+    const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float rx = r[0] / angle, ry = r[1] / angle, rz = r[2] / angle;
+    const float c = cosf(angle), s = sinf(angle);
+    const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+    float KK[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            KK[i * 3 + j] = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+    const float omc = 1.0f - c;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * K[i] + omc * KK[i];
+}
+
+__global__ __launch_bounds__(64) void flame_prologue(FlameDev m, int B, const float* __restrict__ shape, int ns_in,
+                                                      const float* __restrict__ expr, int ne_in,
+                                                      const float* __restrict__ gpose, const float* __restrict__ neck,
+                                                      const float* __restrict__ jaw, const float* __restrict__ eye,
+                                                      float* __restrict__ coef, float* __restrict__ amat,
+                                                      int32_t* __restrict__ lut) {
+    __shared__ float sb[1024];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nb = m.n_shape + m.n_exp;
+    float* crow = coef + (size_t)b * m.KP;
+    for (int k = lane; k < m.KP; k += 64) {
+        float v = 0.f;
+        if (k < m.n_shape) v = (k < ns_in) ? shape[(size_t)b * ns_in + k] : 0.f;
+        else if (k < nb) { const int e = k - m.n_shape; v = (e < ne_in) ? expr[(size_t)b * ne_in + e] : 0.f; }
+        if (k < nb) sb[k] = v;
+        if (k < nb || k >= nb + 36) crow[k] = v;
+    }
+    __syncthreads();
+    // joints: J = J_regressor.v_template + (J_regressor.shapedirs).betas   (lbs.py:188 with the regressor folded at load)
+    float J[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        float p = 0.f;
+        const float* jd = m.jdirs + (size_t)j * nb;
+        for (int k = lane; k < nb; k += 64) p = fmaf(jd[k], sb[k], p);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        J[j] = m.jtemplate[j] + p;
+    }
+    if (lane != 0) return;
+
+    float pose[15];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        pose[i] = gpose[b * 3 + i];
+        pose[3 + i] = neck ? neck[b * 3 + i] : 0.f;
+        pose[6 + i] = jaw[b * 3 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pose[9 + i] = eye ? eye[b * 6 + i] : 0.f;
+
+    float R[5][9];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) rodrigues(pose + 3 * j, R[j]);
+    // pose_feature = (R[1:] - I).view(36)   (lbs.py:197)
+#pragma unroll
+    for (int j = 1; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) crow[nb + (j - 1) * 9 + i] = R[j][i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+
+    // kinematic chain, parents = (-1,0,1,1,1)   (lbs.py:341-378).  Racc/t = accumulated rotation / translation.
+    const int parent[5] = {-1, 0, 1, 1, 1};
+    float Racc[5][9], t[5][3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Racc[0][i] = R[0][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[0][i] = J[i];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) {
+        const int p = parent[j];
+        float rel[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rel[i] = J[j * 3 + i] - J[p * 3 + i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Racc[j][r * 3 + c] = Racc[p][r * 3 + 0] * R[j][0 * 3 + c] + Racc[p][r * 3 + 1] * R[j][1 * 3 + c] +
+                                     Racc[p][r * 3 + 2] * R[j][2 * 3 + c];
+            t[j][r] = Racc[p][r * 3 + 0] * rel[0] + Racc[p][r * 3 + 1] * rel[1] + Racc[p][r * 3 + 2] * rel[2] + t[p][r];
+        }
+    }
+    // A_j = [Racc_j | t_j - Racc_j.J_j]   (lbs.py:375-376), stored row-major 3x4
+    float* A = amat + (size_t)b * 60;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float rj = Racc[j][r * 3 + 0] * J[j * 3 + 0] + Racc[j][r * 3 + 1] * J[j * 3 + 1] +
+                             Racc[j][r * 3 + 2] * J[j * 3 + 2];
+            A[j * 12 + r * 4 + 0] = Racc[j][r * 3 + 0];
+            A[j * 12 + r * 4 + 1] = Racc[j][r * 3 + 1];
+            A[j * 12 + r * 4 + 2] = Racc[j][r * 3 + 2];
+            A[j * 12 + r * 4 + 3] = t[j][r] - rj;
+        }
+    // dynamic contour LUT row (FLAME.py:137-153): rel = R_global . R_neck; yaw = atan2(-rel[2][0], sqrt(rel00^2+rel10^2))
+    const float r00 = R[0][0] * R[1][0] + R[0][1] * R[1][3] + R[0][2] * R[1][6];
+    const float r10 = R[0][3] * R[1][0] + R[0][4] * R[1][3] + R[0][5] * R[1][6];
+    const float r20 = R[0][6] * R[1][0] + R[0][7] * R[1][3] + R[0][8] * R[1][6];
+    const float sy = sqrtf(r00 * r00 + r10 * r10);
+    const float deg = (atan2f(-r20, sy) * 180.0f) / 3.14159274101257324f;   // two fp32 ops, as torch does
+    const int y = (int)rintf(fminf(deg, 39.0f));                              // torch.round = half-to-even
+    int idx;
+    if (y < 0) idx = (y < -39) ? 78 : (39 - y); else idx = y;
+    lut[b] = idx;
+}
+
+__global__ __launch_bounds__(256) void flame_blend_skin(FlameDev m, int B, const float* __restrict__ coef,
+                                                        const float* __restrict__ amat,
+                                                        const float* __restrict__ eyelid, float* __restrict__ verts) {
+    __shared__ __attribute__((aligned(16))) float smem[(FL_BM + 3 * FL_BV) * FL_LDS_STRIDE];
+    float* As = smem;
+    float* Bs = smem + FL_BM * FL_LDS_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v0 = blockIdx.x * FL_BV, b0 = blockIdx.y * FL_BM;
+    const int KP = m.KP;
+
+    // staging assignment: A tile 128 rows x 8 float4, B tile 96 rows x 8 float4
+    const int a_col = tid & 7, a_row = tid >> 3;                       // rows a_row + 32p
+    f32x4 ra[4], rb[3];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int b = b0 + a_row + 32 * p;
+            ra[p] = (b < B) ? *(const f32x4*)(coef + (size_t)b * KP + k0 + a_col * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int row = a_row + 32 * p;                              // plane p, vertex a_row
+            rb[p] = *(const f32x4*)(m.dirs + ((size_t)p * m.VP + v0 + a_row) * KP + k0 + a_col * 4);
+            (void)row;
+        }
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    load_chunk(0);
+    const int nchunk = KP / FL_BK;
+    const int fr = lane & 31, kh = (lane >> 5) * 4;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *(f32x4*)(As + (a_row + 32 * p) * FL_LDS_STRIDE + a_col * 4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(f32x4*)(Bs + (a_row + 32 * p) * FL_LDS_STRIDE + a_col * 4) = rb[p];
+        __syncthreads();
+        if (ch + 1 < nchunk) load_chunk((ch + 1) * FL_BK);
+#pragma unroll
+        for (int kk = 0; kk < FL_BK / 8; ++kk) {
+            const f32x4 a = *(const f32x4*)(As + (wave * 32 + fr) * FL_LDS_STRIDE + kk * 8 + kh);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 bb = *(const f32x4*)(Bs + (c * 32 + fr) * FL_LDS_STRIDE + kk * 8 + kh);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bb[t], acc[c], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: + template, blend 5 joint transforms, apply, + eyelids ------------------------------------------
+    __syncthreads();
+    for (int i = tid; i < FL_BM * 60; i += 256) {
+        const int b = b0 + i / 60;
+        smem[i] = (b < B) ? amat[(size_t)b0 * 60 + i] : 0.f;
+    }
+    __syncthreads();
+    const int v = v0 + fr;
+    if (v >= m.V) return;
+    float w[5], vt[3], le[3], re[3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[j] = m.lbs_weights[(size_t)v * 5 + j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        vt[c] = m.v_template[(size_t)v * 3 + c];
+        le[c] = m.l_eyelid[(size_t)v * 3 + c];
+        re[c] = m.r_eyelid[(size_t)v * 3 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int fb = wave * 32 + mfma32_row(r, lane);
+        const int b = b0 + fb;
+        if (b >= B) continue;
+        const float x = acc[0][r] + vt[0], y = acc[1][r] + vt[1], z = acc[2][r] + vt[2];
+        const float* A = smem + fb * 60;
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            float s = w[0] * A[i];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) s = fmaf(w[j], A[j * 12 + i], s);
+            T[i] = s;
+        }
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = fmaf(T[c * 4 + 2], z, fmaf(T[c * 4 + 1], y, T[c * 4 + 0] * x)) + T[c * 4 + 3];
+        if (eyelid) {
+            const float e0 = eyelid[b * 2 + 0], e1 = eyelid[b * 2 + 1];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = (o[c] + re[c] * e1) + le[c] * e0;   // right uses [:,1], left [:,0] (FLAME.py:285-286)
+        }
+        float* dst = verts + ((size_t)b * m.V + v) * 3;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    }
+}
+
+__device__ inline void lmk_one(const float* __restrict__ vb, const int32_t* __restrict__ faces, int f,
+                               const float* __restrict__ bc, float* __restrict__ out) {
+    const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+    const float b0 = bc[0], b1 = bc[1], b2 = bc[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = (vb[i0 * 3 + c] * b0 + vb[i1 * 3 + c] * b1) + vb[i2 * 3 + c] * b2;
+}
+
+__global__ __launch_bounds__(256) void flame_landmarks(FlameDev m, int B, const float* __restrict__ verts,
+                                                       const int32_t* __restrict__ lut, float* __restrict__ fan,
+                                                       float* __restrict__ fan3d, float* __restrict__ mp) {
+    const int b = blockIdx.x;
+    const float* vb = verts + (size_t)b * m.V * 3;
+    const int nfan = m.n_dyn + m.n_static, total = nfan + m.n_full + m.n_mp;
+    const int row = lut[b];
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        if (i < m.n_dyn) {
+            lmk_one(vb, m.faces, m.dyn_faces[row * m.n_dyn + i], m.dyn_bary + ((size_t)row * m.n_dyn + i) * 3,
+                    fan + ((size_t)b * nfan + i) * 3);
+        } else if (i < nfan) {
+            const int s = i - m.n_dyn;
+            lmk_one(vb, m.faces, m.static_faces[s], m.static_bary + s * 3, fan + ((size_t)b * nfan + i) * 3);
+        } else if (i < nfan + m.n_full) {
+            const int s = i - nfan;
+            lmk_one(vb, m.faces, m.full_faces[s], m.full_bary + s * 3, fan3d + ((size_t)b * m.n_full + s) * 3);
+        } else {
+            const int s = i - nfan - m.n_full;
+            lmk_one(vb, m.faces, m.mp_faces[s], m.mp_bary + s * 3, mp + ((size_t)b * m.n_mp + s) * 3);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void v2l_kernel(const float* __restrict__ verts, int B, int V,
+                                                  const int32_t* __restrict__ faces, const int32_t* __restrict__ fidx,
+                                                  const float* __restrict__ bary, int L, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L) return;
+    const int b = (int)(i / L);
+    lmk_one(verts + (size_t)b * V * 3, faces, fidx[i], bary + i * 3, out + i * 3);
+}
+
+static FlameDev to_dev(const SmirkFlameModel* m) {
+    FlameDev d;
+    d.V = m->V; d.VP = m->VP; d.F = m->F; d.n_shape = m->n_shape; d.n_exp = m->n_exp; d.KP = m->KP;
+    d.n_static = m->n_static; d.n_dyn = m->n_dyn; d.n_lut = m->n_lut; d.n_full = m->n_full; d.n_mp = m->n_mp;
+    d.dirs = m->dirs; d.v_template = m->v_template; d.lbs_weights = m->lbs_weights; d.jdirs = m->jdirs;
+    d.jtemplate = m->jtemplate; d.l_eyelid = m->l_eyelid; d.r_eyelid = m->r_eyelid; d.faces = m->faces;
+    d.static_faces = m->static_faces; d.dyn_faces = m->dyn_faces; d.full_faces = m->full_faces; d.mp_faces = m->mp_faces;
+    d.static_bary = m->static_bary; d.dyn_bary = m->dyn_bary; d.full_bary = m->full_bary; d.mp_bary = m->mp_bary;
+    return d;
+}
+
+extern "C" size_t smirk_flame_workspace_bytes(const SmirkFlameModel* m, int B) {
+    if (!m || B <= 0) return 0;
+    return smirk_align_up((size_t)B * m->KP * 4, 256) + smirk_align_up((size_t)B * 60 * 4, 256) +
+           smirk_align_up((size_t)B * 4, 256);
+}
+
+extern "C" int smirk_flame_forward(const SmirkFlameModel* m, int B, const float* shape, int ns_in, const float* expr,
+                                   int ne_in, const float* global_pose, const float* neck, const float* jaw,
+                                   const float* eye, const float* eyelid, float* verts, float* lmk_fan,
+                                   float* lmk_fan3d, float* lmk_mp, int32_t* lut_idx_out, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    if (!m || B <= 0 || !shape || !expr || !global_pose || !jaw || !verts || !lmk_fan || !lmk_fan3d || !lmk_mp || !ws)
+        return SMIRK_ERR_BAD_ARG;
+    if (m->KP % FL_BK || m->VP % FL_BV || m->VP < m->V || m->n_shape + m->n_exp + 36 > m->KP ||
+        m->n_shape + m->n_exp > 1024 || ns_in > m->n_shape || ne_in > m->n_exp || ns_in < 0 || ne_in < 0)
+        return SMIRK_ERR_BAD_ARG;
+    if (ws_bytes < smirk_flame_workspace_bytes(m, B)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)ws;
+    float* coef = (float*)p; p += smirk_align_up((size_t)B * m->KP * 4, 256);
+    float* amat = (float*)p; p += smirk_align_up((size_t)B * 60 * 4, 256);
+    int32_t* lut = (int32_t*)p;
+    const FlameDev d = to_dev(m);
+    hipLaunchKernelGGL(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw,
+                       eye, coef, amat, lut);
+    dim3 grid(m->VP / FL_BV, (B + FL_BM - 1) / FL_BM);
+    hipLaunchKernelGGL(flame_blend_skin, grid, dim3(256), 0, st, d, B, coef, amat, eyelid, verts);
+    hipLaunchKernelGGL(flame_landmarks, dim3(B), dim3(256), 0, st, d, B, verts, lut, lmk_fan, lmk_fan3d, lmk_mp);
+    if (lut_idx_out) {
+        hipError_t e = hipMemcpyAsync(lut_idx_out, lut, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return SMIRK_ERR_LAUNCH;
+    }
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_vertices2landmarks(const float* verts, int B, int V, const int32_t* faces, const int32_t* faces_idx,
+                                        const float* bary, int L, float* out, void* stream) {
+    if (!verts || !faces || !faces_idx || !bary || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
+    const size_t n = (size_t)B * L;
+    hipLaunchKernelGGL(v2l_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, B, V,
+                       faces, faces_idx, bary, L, out);
+    return smirk_launch_status();
+}
