@@ -95,6 +95,11 @@ class FLAME(nn.Module):
         nbuf('_k_full_faces', self.full_lmk_faces_idx.numpy().reshape(-1).astype(np.int32))
         nbuf('_k_mp_faces', self.mp_lmk_faces_idx.numpy().astype(np.int32))
         nbuf('_k_full_bary', self.full_lmk_bary_coords.numpy().reshape(-1, 3).astype(np.float32))
+        nbuf('_k_static_bary', self.lmk_bary_coords.numpy().astype(np.float32))
+        nbuf('_k_dyn_bary', self.dynamic_lmk_bary_coords.numpy().astype(np.float32))
+        nbuf('_k_mp_bary', self.mp_lmk_bary_coords.numpy().astype(np.float32))
+        nbuf('_k_v_template', v_template)
+        nbuf('_k_lbs_weights', lbs_weights)
         self._dims = dict(V=V, VP=VP, F=faces.shape[0], n_shape=n_shape, n_exp=n_exp, KP=KP,
                           n_static=self.lmk_faces_idx.shape[0], n_dyn=self.dynamic_lmk_faces_idx.shape[1],
                           n_lut=self.dynamic_lmk_faces_idx.shape[0], n_full=self._k_full_faces.shape[0],
@@ -105,7 +110,7 @@ class FLAME(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     def _struct(self):
-        key = (self._k_dirs.data_ptr(), self.v_template.data_ptr())
+        key = (self._k_dirs.data_ptr(), self._k_v_template.data_ptr())
         if self._model_struct is None or self._model_key != key:
             if not self._k_dirs.is_cuda:
                 raise L.SmirkHipError("FLAME module is on the CPU: move it to the HIP device (.to('cuda')); there is no CPU path")
@@ -114,13 +119,13 @@ class FLAME(nn.Module):
                 setattr(m, k, v)
             P = L.ptr
             I = torch.int32
-            m.dirs, m.v_template, m.lbs_weights = P(self._k_dirs), P(self.v_template), P(self.lbs_weights)
+            m.dirs, m.v_template, m.lbs_weights = P(self._k_dirs), P(self._k_v_template), P(self._k_lbs_weights)
             m.jdirs, m.jtemplate = P(self._k_jdirs), P(self._k_jtemplate)
             m.l_eyelid, m.r_eyelid, m.faces = P(self._k_l_eyelid), P(self._k_r_eyelid), P(self._k_faces, I)
-            m.static_faces, m.static_bary = P(self._k_static_faces, I), P(self.lmk_bary_coords)
-            m.dyn_faces, m.dyn_bary = P(self._k_dyn_faces, I), P(self.dynamic_lmk_bary_coords)
+            m.static_faces, m.static_bary = P(self._k_static_faces, I), P(self._k_static_bary)
+            m.dyn_faces, m.dyn_bary = P(self._k_dyn_faces, I), P(self._k_dyn_bary)
             m.full_faces, m.full_bary = P(self._k_full_faces, I), P(self._k_full_bary)
-            m.mp_faces, m.mp_bary = P(self._k_mp_faces, I), P(self.mp_lmk_bary_coords)
+            m.mp_faces, m.mp_bary = P(self._k_mp_faces, I), P(self._k_mp_bary)
             self._model_struct, self._model_key = m, key
         return self._model_struct
 

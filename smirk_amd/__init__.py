@@ -7,5 +7,8 @@ There is no CPU or eager-PyTorch fallback: calls raise if the library is not bui
 """
 from ._lib import SmirkHipError, lib  # noqa: F401
 from .FLAME import FLAME  # noqa: F401
+from .renderer import Renderer  # noqa: F401
+from .smirk_encoder import SmirkEncoder  # noqa: F401
+from .smirk_generator import SmirkGenerator  # noqa: F401
 
-__all__ = ["FLAME", "SmirkHipError", "lib"]
+__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib"]

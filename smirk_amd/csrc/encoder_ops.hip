@@ -1,0 +1,157 @@
+// Memory-bound pieces of the MobileNetV3-minimal encoders (timm tf_mobilenetv3_*_minimal_100; smirk_encoder.py:7-12,34-110)
+// for MI355X (gfx950).  The 1x1 (pointwise) convolutions run on the MFMA implicit-GEMM kernel in conv.hip; here are the
+// 3->16 stride-2 stem, the depthwise 3x3 stencils (TF 'same' padding), global-average-pool + Linear heads and the
+// ExpressionEncoder output clamps.  All NHWC fp32, 16-byte vectors over channels, BatchNorm(eval) folded into scale/shift.
+// Bound: HBM (each activation read once, written once).
+#include "common.h"
+
+// TF 'SAME' leading pad for kernel 3: total = max((ceil(n/s)-1)*s + 3 - n, 0); leading = total/2
+__host__ __device__ static inline int same_pad_lead(int n, int s) {
+    const int o = (n + s - 1) / s;
+    int t = (o - 1) * s + 3 - n;
+    if (t < 0) t = 0;
+    return t / 2;
+}
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float* __restrict__ out, int B, int H, int W, int Cout) {
+    extern __shared__ float sw[];   // [27][Cout] transposed weights, then scale[Cout], shift[Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) { const int k = i / Cout, co = i % Cout; sw[i] = w[co * 27 + k]; }
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) { sw[27 * Cout + i] = scale[i]; sw[28 * Cout + i] = shift[i]; }
+    __syncthreads();
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pt = same_pad_lead(H, 2), pl = same_pad_lead(W, 2);
+    const size_t total = (size_t)B * Ho * Wo, HW = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+        const size_t b = i / ((size_t)Wo * Ho);
+        float x[27];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * 2 - pt + ky, ix = ox * 2 - pl + kx;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? img[(b * 3 + c) * HW + (size_t)iy * W + ix] : 0.f;
+            }
+        float* o = out + i * Cout;
+        for (int co = 0; co < Cout; co += 4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 27; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(x[k], sw[k * Cout + co + q], acc[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaxf(acc[q] * sw[27 * Cout + co + q] + sw[28 * Cout + co + q], 0.f);
+            *(f32x4*)(o + co) = acc;
+        }
+    }
+}
+
+extern "C" int smirk_stem_conv_s2(const float* img, const float* w, const float* scale, const float* shift, float* out,
+                                  int B, int H, int W, int Cout, void* stream) {
+    if (!img || !w || !scale || !shift || !out || B <= 0 || Cout % 4 || Cout <= 0 || Cout > 64) return SMIRK_ERR_BAD_ARG;
+    const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), (size_t)29 * Cout * 4, (hipStream_t)stream, img, w, scale,
+                       shift, out, B, H, W, Cout);
+    return smirk_launch_status();
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const f32x4* __restrict__ in, const f32x4* __restrict__ w,
+                                                        const f32x4* __restrict__ scale, const f32x4* __restrict__ shift,
+                                                        f32x4* __restrict__ out, int B, int H, int W, int C4, int stride,
+                                                        int relu) {
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const int pt = stride == 1 ? 1 : same_pad_lead(H, stride), pl = stride == 1 ? 1 : same_pad_lead(W, stride);
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const size_t b = t / Ho;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - pt + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - pl + kx;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = in[((b * H + iy) * W + ix) * C4 + c];
+                const f32x4 ww = w[(ky * 3 + kx) * C4 + c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[q], ww[q], acc[q]);
+            }
+        }
+        const f32x4 sc = scale[c], sh = shift[c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[q] * sc[q] + sh[q];
+            acc[q] = relu ? fmaxf(v, 0.f) : v;
+        }
+        out[i] = acc;
+    }
+}
+
+extern "C" int smirk_dwconv3x3(const float* in, const float* w, const float* scale, const float* shift, float* out, int B,
+                               int H, int W, int C, int stride, int relu, void* stream) {
+    if (!in || !w || !scale || !shift || !out || B <= 0 || C % 4 || C <= 0 || (stride != 1 && stride != 2))
+        return SMIRK_ERR_BAD_ARG;
+    const size_t total = (size_t)B * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * (C / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)in, (const f32x4*)w,
+                       (const f32x4*)scale, (const f32x4*)shift, (f32x4*)out, B, H, W, C / 4, stride, relu);
+    return smirk_launch_status();
+}
+
+// one workgroup per face: pooled[c] = mean over HW (LDS), then one wave per output neuron (lanes over c, shuffle reduce)
+__global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int HW,
+                                                         int C, int N) {
+    extern __shared__ float pooled[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* f = feat + (size_t)b * HW * C;
+    for (int c = tid; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += f[(size_t)p * C + c];
+        pooled[c] = s / (float)HW;
+    }
+    __syncthreads();
+    for (int n = wave; n < N; n += 4) {
+        const float* wr = w + (size_t)n * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(pooled[c], wr[c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) out[(size_t)b * N + n] = s + (bias ? bias[n] : 0.f);
+    }
+}
+
+extern "C" int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C,
+                                int N, void* stream) {
+    if (!feat || !w || !out || B <= 0 || HW <= 0 || C <= 0 || N <= 0 || C > 8192) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gap_linear_kernel, dim3(B), dim3(256), (size_t)C * 4, (hipStream_t)stream, feat, w, bias, out, HW, C, N);
+    return smirk_launch_status();
+}
+
+__global__ void expression_clamps_kernel(float* __restrict__ p, int B, int n_exp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* r = p + (size_t)b * (n_exp + 5);
+    r[n_exp + 0] = fminf(fmaxf(r[n_exp + 0], 0.f), 1.f);
+    r[n_exp + 1] = fminf(fmaxf(r[n_exp + 1], 0.f), 1.f);
+    r[n_exp + 2] = fmaxf(r[n_exp + 2], 0.f);
+    r[n_exp + 3] = fminf(fmaxf(r[n_exp + 3], -0.2f), 0.2f);
+    r[n_exp + 4] = fminf(fmaxf(r[n_exp + 4], -0.2f), 0.2f);
+}
+
+extern "C" int smirk_expression_clamps(float* params, int B, int n_exp, void* stream) {
+    if (!params || B <= 0 || n_exp < 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(expression_clamps_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, B, n_exp);
+    return smirk_launch_status();
+}

@@ -1,0 +1,272 @@
+// Renderer for MI355X (gfx950) — compiled with -ffp-contract=off: the rasteriser must reproduce the reference's
+// un-fused fp32 mul/sub/add/div sequence bit for bit (pix_to_face parity), see SURVEY.md App. B.
+//
+//   render_project     orthographic camera + y/z flip                         (util.py:64-78, renderer.py:101-102)
+//   render_normals     area-weighted vertex normals by CSR gather in the reference's index_add_ order — deterministic,
+//                      no atomics                                               (util.py:30-62)
+//   raster_face_setup  per face: 3 screen-space corners (sub-mesh select, z+10, xy negation) + conservative pixel bbox
+//                                                                               (renderer.py:139-144,172-173)
+//   raster_tile        one workgroup per 32x8 pixel tile: bin the mesh's faces against the tile into an LDS list, then every
+//                      lane owns ONE pixel and walks the list (LDS-staged face records) keeping the lexicographic minimum
+//                      (z, face) — the reference's K=1 rule — and finally shades its pixel: barycentric normal
+//                      interpolation + 5 directional Lambert lights.  No global atomics, every output byte written once,
+//                      coalesced.  Replaces pytorch3d rasterize_meshes + the [N,H,W,1,3,6] gather of renderer.py:194-206
+//                      (925 MB at B=256 in the reference) + add_directionlight (renderer.py:239-250).
+//
+// Bound: HBM/L2 (integer + fp32 scan work).  Algorithmic bytes per face (image): verts in 60 KB, image out 602 KB.
+#include "common.h"
+
+#define TILE_W 32
+#define TILE_H 8
+#define FACE_CHUNK 64
+#define K_EPS 1e-8f
+
+struct MeshDev {
+    int V, Vf, Ff, nnz;
+    const int32_t *keep, *faces, *nrm_ptr, *nrm_face, *nrm_corner;
+};
+
+__global__ __launch_bounds__(256) void render_project(const float* __restrict__ verts, const float* __restrict__ cam,
+                                                      int B, int V, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * V) return;
+    const int b = (int)(i / V);
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+    const float x = verts[i * 3 + 0], y = verts[i * 3 + 1], z = verts[i * 3 + 2];
+    out[i * 3 + 0] = s * (x + tx);
+    out[i * 3 + 1] = -(s * (y + ty));
+    out[i * 3 + 2] = -(s * z);
+}
+
+__global__ __launch_bounds__(256) void project_landmarks(const float* __restrict__ lmk, const float* __restrict__ cam,
+                                                         int B, int L, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L) return;
+    const int b = (int)(i / L);
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+    out[i * 2 + 0] = s * (lmk[i * 3 + 0] + tx);
+    out[i * 2 + 1] = -(s * (lmk[i * 3 + 1] + ty));
+}
+
+__device__ inline void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ __launch_bounds__(256) void render_normals(MeshDev m, int B, const float* __restrict__ verts,
+                                                      float* __restrict__ normals) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * m.Vf) return;
+    const int b = (int)(i / m.Vf), vi = (int)(i % m.Vf);
+    const float* vb = verts + (size_t)b * m.V * 3;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int e = m.nrm_ptr[vi]; e < m.nrm_ptr[vi + 1]; ++e) {
+        const int f = m.nrm_face[e], c = m.nrm_corner[e];
+        float p[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int g = m.keep[m.faces[f * 3 + k]];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) p[k][d] = vb[g * 3 + d];
+        }
+        // corner c contributes cross(p[c+2] - p[c], p[c+1] - p[c])... spelled per corner as in util.py:52-57
+        const int i0 = c, i1 = (c + 1) % 3, i2 = (c + 2) % 3;
+        float a[3], bb[3], cr[3];
+        // corner1: cross(v2-v1, v0-v1); corner2: cross(v0-v2, v1-v2); corner0: cross(v1-v0, v2-v0)  == cross(p[i1]-p[i0], p[i2]-p[i0])
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { a[d] = p[i1][d] - p[i0][d]; bb[d] = p[i2][d] - p[i0][d]; }
+        cross3(a, bb, cr);
+        n[0] += cr[0]; n[1] += cr[1]; n[2] += cr[2];
+    }
+    const float nrm = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    const float den = fmaxf(nrm, 1e-6f);                                 // F.normalize(eps=1e-6)
+    normals[i * 3 + 0] = n[0] / den;
+    normals[i * 3 + 1] = n[1] / den;
+    normals[i * 3 + 2] = n[2] / den;
+}
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
+
+// face record: 9 floats (x0,y0,z0,x1,y1,z1,x2,y2,z2) in pytorch3d NDC;  bbox: conservative pixel-index box (xi0,xi1,yi0,yi1),
+// empty (xi0 > xi1) for faces the reference skips wholesale (|area| <= eps, zmax < eps).
+__global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H, int W, const float* __restrict__ tv,
+                                                         float* __restrict__ frec, short4* __restrict__ fbox) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * m.Ff) return;
+    const int b = (int)(i / m.Ff), f = (int)(i % m.Ff);
+    const float* tb = tv + (size_t)b * m.V * 3;
+    float p[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int g = m.keep[m.faces[f * 3 + k]];
+        p[k * 3 + 0] = -tb[g * 3 + 0];
+        p[k * 3 + 1] = -tb[g * 3 + 1];
+        p[k * 3 + 2] = tb[g * 3 + 2] + 10.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) frec[i * 9 + k] = p[k];
+    const float xmin = fminf(p[0], fminf(p[3], p[6])), xmax = fmaxf(p[0], fmaxf(p[3], p[6]));
+    const float ymin = fminf(p[1], fminf(p[4], p[7])), ymax = fmaxf(p[1], fmaxf(p[4], p[7]));
+    const float zmax = fmaxf(p[2], fmaxf(p[5], p[8]));
+    const float area = edge_fn(p[0], p[1], p[3], p[4], p[6], p[7]);
+    short4 box = make_short4(1, 0, 1, 0);
+    const bool finite = (xmin == xmin) && (xmax == xmax) && (ymin == ymin) && (ymax == ymax);
+    if (finite && fabsf(area) > K_EPS && !(zmax < K_EPS)) {
+        // pixel column xi sees ndc(W-1-xi); ndc(i) = -1 + (2i+1)/W  =>  i in [ (W(xmin+1)-1)/2 , (W(xmax+1)-1)/2 ], widened by 1
+        float ilo = floorf((W * (xmin + 1.0f) - 1.0f) * 0.5f) - 1.0f, ihi = ceilf((W * (xmax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
+        float jlo = floorf((H * (ymin + 1.0f) - 1.0f) * 0.5f) - 1.0f, jhi = ceilf((H * (ymax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
+        ilo = fminf(fmaxf(ilo, 0.f), (float)(W - 1)); ihi = fminf(fmaxf(ihi, -1.f), (float)(W - 1));
+        jlo = fminf(fmaxf(jlo, 0.f), (float)(H - 1)); jhi = fminf(fmaxf(jhi, -1.f), (float)(H - 1));
+        if (!(xmax < -1.0f || xmin > 1.0f || ymax < -1.0f || ymin > 1.0f))
+            box = make_short4((short)(W - 1 - (int)ihi), (short)(W - 1 - (int)ilo), (short)(H - 1 - (int)jhi),
+                              (short)(H - 1 - (int)jlo));
+    }
+    fbox[i] = box;
+}
+
+__global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int W, const float* __restrict__ frec,
+                                                   const short4* __restrict__ fbox, const float* __restrict__ normals,
+                                                   float* __restrict__ img, long long* __restrict__ p2f_out,
+                                                   float* __restrict__ bary_out, float* __restrict__ zbuf_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    // layout: [FACE_CHUNK*9 floats][FACE_CHUNK ints][1 int counter (+3 pad)][Ff uint16 list]
+    float* sface = (float*)dyn_smem;
+    int* sfid = (int*)(sface + FACE_CHUNK * 9);
+    int* scount = sfid + FACE_CHUNK;
+    unsigned short* slist = (unsigned short*)(scount + 4);
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W;
+    const int b = blockIdx.y;
+    const int tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
+    const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
+    if (tid == 0) *scount = 0;
+    __syncthreads();
+    const short4* boxes = fbox + (size_t)b * m.Ff;
+    for (int f = tid; f < m.Ff; f += 256) {
+        const short4 bx = boxes[f];
+        if (bx.x <= tx1 && bx.y >= tx0 && bx.z <= ty1 && bx.w >= ty0 && bx.x <= bx.y) {
+            const int slot = atomicAdd(scount, 1);
+            slist[slot] = (unsigned short)f;
+        }
+    }
+    __syncthreads();
+    const int n = *scount;
+
+    const int xi = tx0 + (tid & (TILE_W - 1)), yi = ty0 + (tid / TILE_W);
+    const bool live = (xi < W) && (yi < H);
+    const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
+    float best_z = 0.f, bw0 = -1.f, bw1 = -1.f, bw2 = -1.f;
+    int best_f = -1;
+    const float* fr = frec + (size_t)b * m.Ff * 9;
+    for (int base = 0; base < n; base += FACE_CHUNK) {
+        const int cnt = min(FACE_CHUNK, n - base);
+        __syncthreads();
+        for (int i = tid; i < cnt * 9; i += 256) sface[i] = fr[(size_t)slist[base + i / 9] * 9 + (i % 9)];
+        if (tid < cnt) sfid[tid] = slist[base + tid];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const float* v = sface + j * 9;
+            const float x0 = v[0], y0 = v[1], z0 = v[2], x1 = v[3], y1 = v[4], z1 = v[5], x2 = v[6], y2 = v[7], z2 = v[8];
+            const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
+            const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+            if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+            const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+            const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+            const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+            const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+            const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+            if (pz < 0) continue;
+            if (!((w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f))) continue;
+            const int f = sfid[j];
+            if (best_f < 0 || pz < best_z || (pz == best_z && f < best_f)) {
+                best_z = pz; best_f = f; bw0 = w0; bw1 = w1; bw2 = w2;
+            }
+        }
+    }
+    if (!live) return;
+    // ---- resolve + shade (renderer.py:150-166,194-206,239-250) -------------------------------------------------------
+    float shaded = 0.f;
+    if (best_f >= 0) {
+        const float* nb = normals + (size_t)b * m.Vf * 3;
+        const int i0 = m.faces[best_f * 3 + 0], i1 = m.faces[best_f * 3 + 1], i2 = m.faces[best_f * 3 + 2];
+        float nimg[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nimg[c] = (bw0 * nb[i0 * 3 + c] + bw1 * nb[i1 * 3 + c]) + bw2 * nb[i2 * 3 + c];
+        const float grey = 180.0f / 255.0f;
+        const float albedo = (bw0 * grey + bw1 * grey) + bw2 * grey;
+        const float q = 0.57735026918962576f;   // 1/sqrt(3): F.normalize of (+-1,+-1,1)
+        const float lx[5] = {-q, q, -q, q, 0.f}, ly[5] = {q, q, -q, -q, 0.f}, lz[5] = {q, q, q, q, 1.f};
+        float sh = 0.f;
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            float t = (nimg[0] * lx[l] + nimg[1] * ly[l]) + nimg[2] * lz[l];
+            t = fminf(fmaxf(t, 0.f), 1.f) * 1.7f;
+            sh = (l == 0) ? t : sh + t;
+        }
+        sh = sh / 5.0f;
+        shaded = albedo * sh;
+    }
+    const size_t pix = (size_t)yi * W + xi, plane = (size_t)H * W;
+    float* ib = img + (size_t)b * 3 * plane;
+    ib[pix] = shaded; ib[plane + pix] = shaded; ib[2 * plane + pix] = shaded;
+    const size_t o = (size_t)b * plane + pix;
+    if (p2f_out) p2f_out[o] = best_f >= 0 ? (long long)b * m.Ff + best_f : -1ll;
+    if (zbuf_out) zbuf_out[o] = best_f >= 0 ? best_z : -1.f;
+    if (bary_out) { bary_out[o * 3 + 0] = bw0; bary_out[o * 3 + 1] = bw1; bary_out[o * 3 + 2] = bw2; }
+}
+
+static MeshDev mesh_dev(const SmirkRenderMesh* m) {
+    MeshDev d;
+    d.V = m->V; d.Vf = m->Vf; d.Ff = m->Ff; d.nnz = m->nnz;
+    d.keep = m->keep; d.faces = m->faces; d.nrm_ptr = m->nrm_ptr; d.nrm_face = m->nrm_face; d.nrm_corner = m->nrm_corner;
+    return d;
+}
+
+static size_t ws_normals(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Vf * 12, 256); }
+static size_t ws_frec(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Ff * 36, 256); }
+static size_t ws_fbox(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Ff * 8, 256); }
+
+extern "C" size_t smirk_render_workspace_bytes(const SmirkRenderMesh* mesh, int B, int H, int W) {
+    if (!mesh || B <= 0) return 0;
+    (void)H; (void)W;
+    return ws_normals(mesh, B) + ws_frec(mesh, B) + ws_fbox(mesh, B);
+}
+
+extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, int W, const float* verts,
+                                    const float* cam, float* transformed, float* img, int64_t* pix_to_face, float* bary,
+                                    float* zbuf, float* normals, void* ws, size_t ws_bytes, void* stream) {
+    if (!mesh || !verts || !cam || !transformed || !img || !ws || B <= 0) return SMIRK_ERR_BAD_ARG;
+    if (H != W || H <= 0 || H > 1024 || mesh->Ff > 65535 || mesh->Ff <= 0) return SMIRK_ERR_UNSUPPORTED;
+    if (ws_bytes < smirk_render_workspace_bytes(mesh, B, H, W)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshDev d = mesh_dev(mesh);
+    char* p = (char*)ws;
+    float* nrm = (float*)p; p += ws_normals(mesh, B);
+    float* frec = (float*)p; p += ws_frec(mesh, B);
+    short4* fbox = (short4*)p;
+    if (normals) nrm = normals;
+    const size_t nv = (size_t)B * mesh->V, nk = (size_t)B * mesh->Vf, nf = (size_t)B * mesh->Ff;
+    hipLaunchKernelGGL(render_project, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam, B, mesh->V,
+                       transformed);
+    hipLaunchKernelGGL(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
+    hipLaunchKernelGGL(raster_face_setup, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, transformed,
+                       frec, fbox);
+    const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    const size_t smem = FACE_CHUNK * 9 * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
+    hipLaunchKernelGGL(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
+                       (long long*)pix_to_face, bary, zbuf);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_project_landmarks(const float* lmk, const float* cam, int B, int L, float* out, void* stream) {
+    if (!lmk || !cam || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
+    const size_t n = (size_t)B * L;
+    hipLaunchKernelGGL(project_landmarks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lmk, cam,
+                       B, L, out);
+    return smirk_launch_status();
+}

@@ -1,0 +1,257 @@
+"""MI355X drop-in for the reference SmirkEncoder (src/smirk_encoder.py:14-133) and the timm backbones it instantiates
+(timm==0.9.16 `tf_mobilenetv3_{small,large}_minimal_100`, features_only=True — smirk_encoder.py:7-12; timm is NOT a dependency
+of this package: the architecture is decoded here from the published arch strings).
+
+The nn.Module tree only HOLDS parameters under timm's state_dict names (`<enc>.encoder.conv_stem.weight`, `.bn1.*`,
+`.blocks.{stage}.{i}.conv_pw|conv_dw|conv_pwl|conv.weight`, `.bn{1,2,3}.*`, heads `pose_cam_layers.0`, `shape_layers.0`,
+`expression_layers.0`) so the reference's strict checkpoint load (demo.py:56-58) works.  forward() runs on libsmirk_hip.so:
+stem / depthwise / pool+linear as streaming kernels, every pointwise conv on the fp32 MFMA implicit-GEMM kernel with
+BatchNorm(eval) + ReLU + residual fused.  Eval mode only this round.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+BN_EPS = 1e-3   # "tf_" models
+
+_ARCH = {
+    # (block type, repeats, stride, expansion, out channels); every kernel is 3x3 (1x1 for 'cn'), ReLU, no SE ("minimal")
+    "tf_mobilenetv3_large_minimal_100": [
+        [("ds", 1, 1, 1.0, 16)],
+        [("ir", 1, 2, 4.0, 24), ("ir", 1, 1, 3.0, 24)],
+        [("ir", 3, 2, 3.0, 40)],
+        [("ir", 1, 2, 6.0, 80), ("ir", 1, 1, 2.5, 80), ("ir", 2, 1, 2.3, 80)],
+        [("ir", 2, 1, 6.0, 112)],
+        [("ir", 3, 2, 6.0, 160)],
+        [("cn", 1, 1, 1.0, 960)],
+    ],
+    "tf_mobilenetv3_small_minimal_100": [
+        [("ds", 1, 2, 1.0, 16)],
+        [("ir", 1, 2, 4.5, 24), ("ir", 1, 1, 3.67, 24)],
+        [("ir", 1, 2, 4.0, 40), ("ir", 2, 1, 6.0, 40)],
+        [("ir", 2, 1, 3.0, 48)],
+        [("ir", 3, 2, 6.0, 96)],
+        [("cn", 1, 1, 1.0, 576)],
+    ],
+}
+
+
+def _round_channels(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    return new_v + divisor if new_v < 0.9 * v else new_v
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=BN_EPS)
+
+
+class _DS(nn.Module):          # DepthwiseSeparableConv holder
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(cin, cin, 3, stride, 1, groups=cin, bias=False); self.bn1 = _bn(cin)
+        self.conv_pw = nn.Conv2d(cin, cout, 1, bias=False); self.bn2 = _bn(cout)
+        self.kind, self.stride, self.skip = "ds", stride, (stride == 1 and cin == cout)
+
+
+class _IR(nn.Module):          # InvertedResidual holder
+    def __init__(self, cin, cout, stride, exp):
+        super().__init__()
+        mid = _round_channels(cin * exp)
+        self.conv_pw = nn.Conv2d(cin, mid, 1, bias=False); self.bn1 = _bn(mid)
+        self.conv_dw = nn.Conv2d(mid, mid, 3, stride, 1, groups=mid, bias=False); self.bn2 = _bn(mid)
+        self.conv_pwl = nn.Conv2d(mid, cout, 1, bias=False); self.bn3 = _bn(cout)
+        self.kind, self.stride, self.skip = "ir", stride, (stride == 1 and cin == cout)
+
+
+class _CN(nn.Module):          # ConvBnAct holder
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1, bias=False); self.bn1 = _bn(cout)
+        self.kind = "cn"
+
+
+class MobileNetV3Features(nn.Module):
+    """Parameter holder + HIP forward for one backbone; returns the last feature map, NHWC [B,h,w,C]."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.conv_stem = nn.Conv2d(3, 16, 3, 2, bias=False)
+        self.bn1 = _bn(16)
+        stages, cin, chans = [], 16, []
+        for st in _ARCH[name]:
+            blocks = []
+            for kind, rep, stride, exp, cout in st:
+                for i in range(rep):
+                    s = stride if i == 0 else 1
+                    blocks.append(_DS(cin, cout, s) if kind == "ds" else _IR(cin, cout, s, exp) if kind == "ir" else _CN(cin, cout))
+                    cin = cout
+            stages.append(nn.Sequential(*blocks))
+            chans.append(cin)
+        self.blocks = nn.Sequential(*stages)
+        self.feature_info = [dict(num_chs=cin)]      # only [-1]['num_chs'] is consulted (smirk_encoder.py:11)
+        self.num_features = cin
+        self._packed, self._packed_key = None, None
+
+    def _key(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    @staticmethod
+    def _affine(bn):
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        return s.contiguous(), (bn.bias.detach().float() - bn.running_mean.detach().float() * s).contiguous()
+
+    def _pack(self):
+        key = self._key()
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        pw = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, conv.in_channels).contiguous()
+        dw = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, 9).t().contiguous()      # [9][C]
+        P = {"stem": (self.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(16, 27).contiguous(),) + self._affine(self.bn1)}
+        for si, st in enumerate(self.blocks):
+            for bi, blk in enumerate(st):
+                k = (si, bi)
+                if blk.kind == "ds":
+                    P[k] = dict(dw=(dw(blk.conv_dw),) + self._affine(blk.bn1), pw=(pw(blk.conv_pw),) + self._affine(blk.bn2))
+                elif blk.kind == "ir":
+                    P[k] = dict(pw=(pw(blk.conv_pw),) + self._affine(blk.bn1), dw=(dw(blk.conv_dw),) + self._affine(blk.bn2),
+                                pwl=(pw(blk.conv_pwl),) + self._affine(blk.bn3))
+                else:
+                    P[k] = dict(pw=(pw(blk.conv),) + self._affine(blk.bn1))
+        self._packed, self._packed_key = P, key
+        return P
+
+    @staticmethod
+    def _pointwise(lib, st, x, pk, relu, residual=None):
+        w, sc, sh = pk
+        B, H, W, C = x.shape
+        d = L.SmirkConvDesc()
+        d.B, d.H, d.W, d.C0, d.C1, d.Cout = B, H, W, C, 0, w.shape[0]
+        d.KH = d.KW = d.stride = 1
+        d.pad_t = d.pad_l = 0
+        d.Ho, d.Wo, d.pad_mode = H, W, L.PAD_ZERO
+        d.act, d.out_mode = (L.ACT_RELU if relu else L.ACT_NONE), L.OUT_NHWC
+        out = torch.empty(B, H, W, w.shape[0], device=x.device)
+        P = L.ptr
+        L.check(lib.smirk_conv_igemm_f32(d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st))
+        return out
+
+    @staticmethod
+    def _depthwise(lib, st, x, pk, stride):
+        w, sc, sh = pk
+        B, H, W, C = x.shape
+        out = torch.empty(B, (H + stride - 1) // stride, (W + stride - 1) // stride, C, device=x.device)
+        P = L.ptr
+        L.check(lib.smirk_dwconv3x3(P(x), P(w), P(sc), P(sh), P(out), B, H, W, C, stride, 1, st))
+        return out
+
+    def forward(self, img):
+        """img [B,3,H,W] NCHW in [0,1] -> last feature map NHWC [B,H/32,W/32,C]."""
+        if self.training:
+            raise NotImplementedError("smirk_amd encoders implement the eval-mode forward only (call .eval())")
+        lib, st, P = L.lib(), L.stream_ptr(), self._pack()
+        img = L.as_f32c(img)
+        B, _, H, W = img.shape
+        w, sc, sh = P["stem"]
+        x = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 16, device=img.device)
+        L.check(lib.smirk_stem_conv_s2(L.ptr(img), L.ptr(w), L.ptr(sc), L.ptr(sh), L.ptr(x), B, H, W, 16, st))
+        for si, stg in enumerate(self.blocks):
+            for bi, blk in enumerate(stg):
+                pk = P[(si, bi)]
+                if blk.kind == "ds":
+                    y = self._depthwise(lib, st, x, pk["dw"], blk.stride)
+                    x = self._pointwise(lib, st, y, pk["pw"], relu=False, residual=x if blk.skip else None)
+                elif blk.kind == "ir":
+                    y = self._pointwise(lib, st, x, pk["pw"], relu=True)
+                    y = self._depthwise(lib, st, y, pk["dw"], blk.stride)
+                    x = self._pointwise(lib, st, y, pk["pwl"], relu=False, residual=x if blk.skip else None)
+                else:
+                    x = self._pointwise(lib, st, x, pk["pw"], relu=True)
+        return x
+
+
+def create_backbone(backbone_name, pretrained=True):
+    """smirk_encoder.py:7-12.  `pretrained` is accepted for signature compatibility; weights always come from the checkpoint
+    the caller loads next (demo.py:55-58) — there is no download path."""
+    backbone = MobileNetV3Features(backbone_name)
+    return backbone, backbone.feature_info[-1]['num_chs']
+
+
+def _head(lib, feat, lin):
+    B, h, w, C = feat.shape
+    W_ = lin.weight.detach().float().contiguous()
+    b_ = lin.bias.detach().float().contiguous()
+    out = torch.empty(B, W_.shape[0], device=feat.device)
+    L.check(lib.smirk_gap_linear(L.ptr(feat), L.ptr(W_), L.ptr(b_), L.ptr(out), B, h * w, C, W_.shape[0], L.stream_ptr()))
+    return out
+
+
+class PoseEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder, feature_dim = create_backbone('tf_mobilenetv3_small_minimal_100')
+        self.pose_cam_layers = nn.Sequential(nn.Linear(feature_dim, 6))
+        self.init_weights()
+
+    def init_weights(self):                                      # smirk_encoder.py:26-31
+        with torch.no_grad():
+            self.pose_cam_layers[-1].weight.mul_(0.001)
+            self.pose_cam_layers[-1].bias.mul_(0.001)
+            self.pose_cam_layers[-1].weight[3] = 0
+            self.pose_cam_layers[-1].bias[3] = 7
+
+    def forward(self, img):
+        pose_cam = _head(L.lib(), self.encoder(img), self.pose_cam_layers[0])
+        return {'pose_params': pose_cam[..., :3], 'cam': pose_cam[..., 3:]}
+
+
+class ShapeEncoder(nn.Module):
+    def __init__(self, n_shape=300):
+        super().__init__()
+        self.encoder, feature_dim = create_backbone('tf_mobilenetv3_large_minimal_100')
+        self.shape_layers = nn.Sequential(nn.Linear(feature_dim, n_shape))
+        self.init_weights()
+
+    def init_weights(self):                                      # smirk_encoder.py:61-63
+        with torch.no_grad():
+            self.shape_layers[-1].weight.mul_(0)
+            self.shape_layers[-1].bias.mul_(0)
+
+    def forward(self, img):
+        return {'shape_params': _head(L.lib(), self.encoder(img), self.shape_layers[0])}
+
+
+class ExpressionEncoder(nn.Module):
+    def __init__(self, n_exp=50):
+        super().__init__()
+        self.encoder, feature_dim = create_backbone('tf_mobilenetv3_large_minimal_100')
+        self.expression_layers = nn.Sequential(nn.Linear(feature_dim, n_exp + 2 + 3))
+        self.n_exp = n_exp
+        self.init_weights()
+
+    def init_weights(self):                                      # smirk_encoder.py:90-92
+        with torch.no_grad():
+            self.expression_layers[-1].weight.mul_(0.1)
+            self.expression_layers[-1].bias.mul_(0.1)
+
+    def forward(self, img):
+        params = _head(L.lib(), self.encoder(img), self.expression_layers[0])
+        L.check(L.lib().smirk_expression_clamps(L.ptr(params), params.shape[0], self.n_exp, L.stream_ptr()))
+        n = self.n_exp
+        return {'expression_params': params[..., :n], 'eyelid_params': params[..., n:n + 2],
+                'jaw_params': params[..., n + 2:n + 5]}
+
+
+class SmirkEncoder(nn.Module):
+    def __init__(self, n_exp=50, n_shape=300):
+        super().__init__()
+        self.pose_encoder = PoseEncoder()
+        self.shape_encoder = ShapeEncoder(n_shape=n_shape)
+        self.expression_encoder = ExpressionEncoder(n_exp=n_exp)
+
+    def forward(self, img):
+        outputs = {}
+        outputs.update(self.pose_encoder(img))
+        outputs.update(self.shape_encoder(img))
+        outputs.update(self.expression_encoder(img))
+        return outputs

@@ -1,0 +1,199 @@
+"""CPU-side checks (`-m "not gpu"`): oracle vs golden vectors, analytic rasteriser KATs, host logic, C-ABI exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import assets as A
+from oracle import generator_ref as G
+from oracle import mobilenet_ref as M
+from oracle import render_ref as R
+from oracle.flame_ref import FlameRef
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- oracle vs committed reference outputs
+def test_flame_oracle_vs_reference_golden(sandbox, golden_dir):
+    g = np.load(os.path.join(golden_dir, "flame_golden.npz"))
+    p = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    o = FlameRef(sandbox).forward(p)
+    assert np.sqrt(((o["vertices"] - g["vertices"]) ** 2).sum(-1)).max() < 1e-6
+    for k in ("landmarks_fan", "landmarks_fan_3d", "landmarks_mp"):
+        assert np.abs(o[k] - g[k]).max() < 1e-6
+
+
+def test_flame_oracle_properties(sandbox):
+    fr = FlameRef(sandbox)
+    z = dict(shape_params=np.zeros((1, 300), np.float32), expression_params=np.zeros((1, 50), np.float32),
+             pose_params=np.zeros((1, 3), np.float32), jaw_params=np.zeros((1, 3), np.float32))
+    assert np.abs(fr.forward(z)["vertices"][0] - fr.v_template).max() < 1e-6      # zero params -> template
+    # pure global rotation rotates rigidly about joint 0
+    p = dict(z, pose_params=np.array([[0.1, 0.3, -0.2]], np.float32))
+    v = fr.forward(p)["vertices"][0]
+    Rm = fr.batch_rodrigues(p["pose_params"])[0]
+    J0 = fr.J_regressor[0] @ fr.v_template
+    assert np.abs(v - ((fr.v_template - J0) @ Rm.T + J0)).max() < 2e-6
+
+
+def test_render_oracle_vs_reference_golden(sandbox, golden_dir):
+    g = np.load(os.path.join(golden_dir, "render_golden.npz"))
+    f = np.load(os.path.join(golden_dir, "flame_golden.npz"))
+    o = R.RendererRef(sandbox).forward(f["vertices"][:2], g["cam"], landmarks_fan=f["landmarks_fan"][:2],
+                                        landmarks_mp=f["landmarks_mp"][:2])
+    assert np.array_equal(o["transformed_vertices"], g["transformed_vertices"])
+    assert np.array_equal(o["landmarks_fan"], g["landmarks_fan"])
+    assert np.abs(o["rendered_img"][:, 0] - g["rendered_ch0"]).max() < 2e-6
+    assert np.array_equal(o["rendered_img"][:, 0] == 0, g["rendered_ch0"] == 0)
+
+
+def test_generator_oracle_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "generator_golden.npz"))
+    sd = G.synth_state_dict()
+    y = G.forward(sd, A.synth_generator_input(1, seed=int(g["seed"]))).numpy()
+    assert np.abs(y[:, :, ::4, ::4] - g["y_sub4"]).max() < 1e-6
+    assert len(sd) == 178
+
+
+def test_encoder_oracle_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "encoder_golden.npz"))
+    sd = M.synth_encoder_state_dict()
+    m = M.SmirkEncoderRef(); m.load_state_dict(sd); m.eval()
+    with torch.no_grad():
+        o = m(A.synth_images(2, seed=int(g["seed"])))
+    for k in ("pose_params", "cam", "shape_params", "expression_params", "eyelid_params", "jaw_params"):
+        assert np.abs(o[k].numpy() - g[k]).max() < 1e-5, k
+
+
+def test_mobilenet_restatement_matches_published_counts():
+    """timm publishes 3.92 M / 2.04 M params for the full models; minus conv_head+classifier that is 1,413,208 / 428,888
+     — the only external anchor available for the un-vendored backbone."""
+    lg, sm = M.create_model("tf_mobilenetv3_large_minimal_100"), M.create_model("tf_mobilenetv3_small_minimal_100")
+    assert sum(p.numel() for p in lg.parameters()) == 1413208
+    assert sum(p.numel() for p in sm.parameters()) == 428888
+    assert sum(p.numel() for p in lg.parameters()) + 960 * 1280 + 1280 + 1280 * 1000 + 1000 == 3924288
+    assert [f["num_chs"] for f in lg.feature_info] == [16, 24, 40, 112, 960]
+    assert [f["num_chs"] for f in sm.feature_info] == [16, 16, 24, 48, 576]
+    assert len(lg.state_dict()) == 276 and len(sm.state_dict()) == 204
+    with torch.no_grad():
+        shapes = [tuple(t.shape[1:]) for t in lg.eval()(torch.zeros(1, 3, 224, 224))]
+    assert shapes == [(16, 112, 112), (24, 56, 56), (40, 28, 28), (112, 14, 14), (960, 7, 7)]
+
+
+# ---------------------------------------------------------------- rasteriser known-answer tests (pytorch3d semantics, App. B)
+def _tri(*pts):
+    return np.asarray(pts, np.float32).reshape(1, -1, 3, 3)
+
+
+def test_raster_kat_axis_aligned_triangle_pixel_count_and_orientation():
+    S = 8
+    # right triangle covering the +x/+y quadrant corner region: vertices in pytorch3d NDC (+X left, +Y up)
+    fv = _tri([[0.0, 0.0, 1.0], [1.0, 0.0, 1.0], [0.0, 1.0, 1.0]])
+    p2f, zb, bary = R.rasterize_naive(fv, S, S)
+    p2n, _, _ = R.rasterize_numpy(fv, S, S)
+    assert np.array_equal(p2f, p2n)
+    # pixel centres are at -1+(2i+1)/8; inside iff x>0,y>0,x+y<1 strictly -> centres (.125,.125),(.375,.125),(.625,.125),(.125,.375),(.375,.375),(.125,.625)
+    assert (p2f >= 0).sum() == 6
+    # +X is LEFT and +Y is UP in the output image: covered pixels sit in the top-left quadrant
+    ys, xs = np.nonzero(p2f[0] >= 0)
+    assert ys.max() < S // 2 and xs.max() < S // 2
+    assert np.allclose(zb[p2f >= 0], 1.0) and (zb[p2f < 0] == -1).all()
+    assert np.allclose(bary[p2f >= 0].sum(-1), 1.0, atol=1e-6)
+
+
+def test_raster_kat_z_order_tie_and_shared_edge():
+    S = 8
+    big_near = [[-1, -1, 1.0], [3, -1, 1.0], [-1, 3, 1.0]]
+    big_far = [[-1, -1, 2.0], [3, -1, 2.0], [-1, 3, 2.0]]
+    p2f, _, _ = R.rasterize_naive(_tri(big_far, big_near), S, S)
+    assert (p2f[p2f >= 0] == 1).all()                                        # nearer face wins regardless of order
+    p2f, _, _ = R.rasterize_naive(_tri(big_near, big_near), S, S)
+    assert (p2f[p2f >= 0] == 0).all()                                        # exact z tie -> lower face index
+    # two triangles sharing the diagonal x == y: pixel centres ON the shared edge belong to neither (strict w > 0)
+    a = [[-1, -1, 1.0], [1, -1, 1.0], [1, 1, 1.0]]
+    b = [[-1, -1, 1.0], [1, 1, 1.0], [-1, 1, 1.0]]
+    p2f, _, _ = R.rasterize_naive(_tri(a, b), S, S)
+    assert (np.diag(p2f[0]) == -1).all() and (p2f[0][~np.eye(S, dtype=bool)] >= 0).all()
+    # back-facing (clockwise) triangles are kept (cull_backfaces=False)
+    p2f, _, _ = R.rasterize_naive(_tri(a[::-1]), S, S)
+    assert (p2f >= 0).sum() > 0
+    # degenerate (zero-area) and behind-camera faces are skipped
+    p2f, _, _ = R.rasterize_naive(_tri([[0, 0, 1.0], [1, 1, 1.0], [.5, .5, 1.0]], [[-1, -1, -2.0], [3, -1, -2.0], [-1, 3, -2.0]]), S, S)
+    assert (p2f == -1).all()
+
+
+def test_raster_c_matches_numpy_on_random_soup():
+    rng = np.random.default_rng(0)
+    fv = rng.uniform(-1.2, 1.2, (2, 40, 3, 3)).astype(np.float32)
+    fv[..., 2] = rng.uniform(0.5, 3, (2, 40, 3))
+    a, b = R.rasterize_naive(fv, 16, 16), R.rasterize_numpy(fv, 16, 16)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+# ---------------------------------------------------------------- host logic / drop-in contract
+def test_generator_state_dict_keys_match_reference_contract():
+    from smirk_amd import SmirkGenerator
+    m = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+    sd = G.synth_state_dict()
+    assert set(m.state_dict().keys()) == set(sd.keys()) and len(sd) == 178
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    assert sum(p.numel() for p in m.parameters()) == 31367171
+
+
+def test_encoder_state_dict_keys_match_timm_layout():
+    from smirk_amd import SmirkEncoder
+    m = SmirkEncoder()
+    ref = M.SmirkEncoderRef()
+    a, b = m.state_dict(), ref.state_dict()
+    assert set(a.keys()) == set(b.keys())
+    for k in a:
+        assert tuple(a[k].shape) == tuple(b[k].shape), k
+    assert {"pose_encoder", "shape_encoder", "expression_encoder"} <= set(dict(m.named_children()))
+    # head inits of smirk_encoder.py:26-31,61-63
+    assert float(m.pose_encoder.pose_cam_layers[0].bias[3]) == 7.0 and float(m.shape_encoder.shape_layers[0].weight.abs().sum()) == 0.0
+
+
+def test_flame_and_renderer_construct_with_reference_buffers(in_sandbox):
+    from smirk_amd import FLAME, Renderer
+    f, r = FLAME(), Renderer()
+    exp = {"faces_tensor": (9976, 3), "v_template": (5023, 3), "shapedirs": (5023, 3, 350), "posedirs": (36, 15069),
+           "J_regressor": (5, 5023), "parents": (5,), "lbs_weights": (5023, 5), "l_eyelid": (1, 5023, 3),
+           "lmk_faces_idx": (51,), "dynamic_lmk_faces_idx": (79, 17), "full_lmk_bary_coords": (1, 68, 3),
+           "mp_lmk_faces_idx": (105,), "eye_pose": (1, 6), "neck_pose": (1, 3), "neck_kin_chain": (2,)}
+    sd = f.state_dict()
+    for k, s in exp.items():
+        assert tuple(sd[k].shape) == s, k
+    assert not any(k.startswith("_k_") for k in sd)
+    assert f.faces_tensor.dtype == torch.int64
+    assert tuple(r.faces.shape) == (1, 3408, 3) and r.image_size == 224 and "face" in r.flame_masks
+    assert tuple(r.face_colors.shape) == (1, 3408, 3, 3)
+    ref = R.RendererRef(in_sandbox)
+    assert np.array_equal(r.faces[0].numpy(), ref.faces)
+    # CSR of the normal gather reproduces the index_add_ order: contributions of a vertex come corner-1 pass first
+    ptr, nf, nc = r._k_nrm_ptr.numpy(), r._k_nrm_face.numpy(), r._k_nrm_corner.numpy()
+    assert ptr[-1] == 3 * 3408
+    for v in (0, 17, 1786):
+        seg = list(zip(nc[ptr[v]:ptr[v + 1]], nf[ptr[v]:ptr[v + 1]]))
+        order = {1: 0, 2: 1, 0: 2}
+        assert seg == sorted(seg, key=lambda t: (order[t[0]], t[1]))
+        assert all(ref.faces[f_, c_] == v for c_, f_ in seg)
+    with pytest.raises(Exception):
+        f.forward({k: torch.from_numpy(v) for k, v in A.synth_flame_params(1).items()})     # CPU tensors: no fallback
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from smirk_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "smirk_hip.h")).read()
+    declared = set(re.findall(r"\b(smirk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m smirk_amd.build`"
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        getattr(dll, name)
+    dll.smirk_strerror.restype = ctypes.c_char_p
+    assert dll.smirk_strerror(0) == b"ok" and dll.smirk_abi_version() == _lib.ABI_VERSION
