@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py — faces/sec of SMIRK's per-frame hot path (encode -> FLAME -> render -> generate) at 224x224 on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_PER_GPU]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the whole path over `--batch` synthetic frames per GPU (default 128 = BASELINE config 4's 1024-frame
+batch sharded over 8 GPUs; weak scaling), inputs resident in HBM, followed by the asynchronous RCCL all-gather of the outputs
+(vertices + rendered + re-synthesised image) which overlaps the next step.  Rank 0 prints ONE JSON line (contract in the task
+statement) carrying `roofline` for the dominant kernel (HIP-event timing of every conv_igemm launch in an extra instrumented step)
+and `cpu_baseline` (the CPU oracle — a port of the reference path — timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_FACE = 28.77e9          # encoder 0.929 G + FLAME 12.7 M + render ~2 M + generator 27.826 G
+PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_modules(sandbox, device):
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator
+    from smirk_amd import synth
+    synth.write_sandbox(sandbox)
+    cwd = os.getcwd()
+    os.chdir(sandbox)
+    try:
+        flame, rend = FLAME(), Renderer()
+    finally:
+        os.chdir(cwd)
+    torch.manual_seed(1234)
+    enc = SmirkEncoder()
+    # random-init weights of the reference architecture (no checkpoint is obtainable offline); the shape head is zero-initialised
+    # by the reference (smirk_encoder.py:61-63) — give it a small std so FLAME sees non-trivial shape coefficients
+    with torch.no_grad():
+        enc.shape_encoder.shape_layers[0].weight.normal_(0, 1e-3)
+        enc.expression_encoder.expression_layers[0].weight.mul_(0.3)
+    gen = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+    mods = [m.to(device).eval() for m in (enc, flame, rend, gen)]
+    return mods
+
+
+def cpu_baseline(sandbox, n_faces):
+    """The oracle (CPU port of the reference path) on `n_faces` frames; returns faces/s.  Checker code, timed beside the GPU."""
+    import numpy as np
+    from oracle import generator_ref as G, mobilenet_ref as M
+    from oracle.flame_ref import FlameRef
+    from oracle.render_ref import RendererRef
+    from smirk_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    encr = M.SmirkEncoderRef().eval()
+    with torch.no_grad():
+        encr.shape_encoder.shape_layers[0].weight.normal_(0, 1e-3)
+    gsd = G.synth_state_dict(calibrate=False)
+    fr, rr = FlameRef(sandbox), RendererRef(sandbox)
+    img = synth.synth_images(n_faces, seed=5)
+    masked = synth.synth_generator_input(n_faces, seed=5)[:, 3:]
+
+    def run():
+        with torch.no_grad():
+            e = encr(img)
+        p = {k: v.numpy() for k, v in e.items()}
+        p["cam"] = np.clip(p["cam"], [6, -.1, -.1], [10, .1, .1]).astype(np.float32)
+        fl = fr.forward(p)
+        r = rr.forward(fl["vertices"], p["cam"])
+        x = torch.cat([torch.from_numpy(r["rendered_img"]), masked], 1)
+        return G.forward(gsd, x)
+
+    run()                                   # warm-up (also builds raster_ref.c if needed)
+    t = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t
+    return n_faces / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--cpu-faces", type=int, default=16, help="sample size of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from smirk_amd import _lib as L, synth
+    from smirk_amd.pipeline import OutputGatherer, SmirkPipeline
+    sandbox = tempfile.mkdtemp(prefix=f"smirk_bench_r{rank}_")
+    enc, flame, rend, gen = build_modules(sandbox, dev)
+    pipe = SmirkPipeline(enc, flame, rend, gen)
+    B = args.batch
+    img = synth.synth_images(B, seed=1000 + rank).to(dev)                  # resident in HBM before the timed region
+    masked = synth.synth_generator_input(B, seed=1000 + rank)[:, 3:].contiguous().to(dev)
+    gather = OutputGatherer()
+
+    def step():
+        out = pipe(img, masked, with_landmarks=True)
+        gather.wait()                       # previous step's all-gather must have landed before its buffers are reused
+        gather.start(out)
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    gather.wait()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    gather.wait()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv_igemm launch --------
+    roof = None
+    if rank == 0:
+        L.TIMER = []
+        step(); gather.wait(); torch.cuda.synchronize()
+        per = {}
+        for name, flops, e0, e1 in L.TIMER:
+            a = per.setdefault(name, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        L.TIMER = None
+        dom = max(per, key=lambda k: per[k][1])
+        fl, tm, n = per[dom]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": fl / tm / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                "frac": fl / tm / PEAK_FP32_MFMA, "traffic": None, "launches_per_step": n,
+                "avg_launch_ms": tm / n * 1e3, "flop_per_launch": fl / n,
+                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]} for k, v in per.items()},
+                "igemm_share_of_step": sum(v[1] for v in per.values()) / (dt / args.steps)}
+
+    if rank == 0:
+        faces = B * world * args.steps
+        value = faces / dt
+        cpu = None
+        if world == 1 and args.cpu_faces > 0:
+            v, cdt = cpu_baseline(sandbox, args.cpu_faces)
+            cpu = {"value": v, "unit": "faces/sec", "cores": os.cpu_count(), "kind": "port",
+                   "sample": f"{args.cpu_faces} synthetic 224x224 frames through the CPU oracle (torch-CPU fp32 encoder+generator on "
+                             f"{os.cpu_count()} threads, numpy FLAME, C rasteriser with OpenMP), 1 warm-up + 1 timed pass = {cdt:.1f} s"}
+        print(json.dumps({
+            "metric": "faces/sec (encode+FLAME+render+generate) @224x224", "value": value, "unit": "faces/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full inference incl. SmirkGenerator re-synthesis (BASELINE config 4: 1024 frames / 8 GPUs)",
+                       "frames_per_gpu": B, "global_batch": B * world, "image": "224x224", "parallelism": f"dp{world}",
+                       "collective": "async all_gather(vertices, rendered_img, reconstructed_img)" if world > 1 else "none (1 GPU)",
+                       "weights": "random-init reference architecture (no checkpoint offline)"},
+            "path_tflops_per_gpu": value / world * FLOP_PER_FACE / 1e12,
+            "path_frac_of_fp32_mfma_peak": value / world * FLOP_PER_FACE / PEAK_FP32_MFMA,
+            "roofline": roof, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,27 @@ def as_f32c(t):
     return t.contiguous()
 
 
+# bench.py sets TIMER to a list to collect per-launch (kernel, algorithmic flop, start, end) HIP events on the launch stream
+TIMER = None
+
+
+def timed(kernel, flops, fn):
+    if TIMER is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    TIMER.append((kernel, flops, e0, e1))
+    return r
+
+
+def igemm_kernel_name(n_gemm):
+    """Which conv_igemm_kernel instantiation smirk_conv_igemm_f32 dispatches for a GEMM N (mirrors conv.hip)."""
+    return "conv_igemm_kernel<128,128,2,2>" if n_gemm > 64 else "conv_igemm_kernel<128,64,2,2>" if n_gemm > 32 \
+        else "conv_igemm_kernel<256,32,4,1>"
+
+
 class Workspace:
     """Grow-only byte scratch buffer owned by a module (the library never allocates)."""
 

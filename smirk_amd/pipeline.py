@@ -1,0 +1,73 @@
+"""End-to-end per-frame path and its data-parallel sharding.
+
+    encode (SmirkEncoder) -> FLAME -> Renderer -> SmirkGenerator           (demo.py:107-112,167-169; smirk_trainer.py:37-48,94)
+
+Frames are independent, every constant is replicated (~163 MB) and there is NO exchange inside the path, so the batch is
+sharded in contiguous slices, one process per GPU; the only collective is an all-gather of the outputs (vertices, rendered and
+re-synthesised images) over RCCL/xGMI, issued asynchronously so it overlaps the next batch's compute.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, rank, world):
+    """Contiguous slice [lo, hi) of `total` frames owned by `rank` (remainder spread over the first ranks)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class SmirkPipeline:
+    """Holds the four drop-in modules; __call__ runs one batch of frames that are already resident on this GPU."""
+
+    def __init__(self, encoder, flame, renderer, generator=None):
+        self.encoder, self.flame, self.renderer, self.generator = encoder, flame, renderer, generator
+
+    @torch.no_grad()
+    def __call__(self, img, masked_img=None, with_landmarks=True):
+        enc = self.encoder(img)
+        fl = self.flame.forward(enc)
+        lm = dict(landmarks_fan=fl['landmarks_fan'], landmarks_mp=fl['landmarks_mp']) if with_landmarks else {}
+        rn = self.renderer.forward(fl['vertices'], enc['cam'], **lm)
+        out = dict(enc)
+        out.update(vertices=fl['vertices'], landmarks_fan_3d=fl['landmarks_fan_3d'], **rn)
+        if self.generator is not None:
+            if masked_img is None:
+                raise ValueError("the generator needs the masked image (utils/masking.py output) next to the rendering")
+            x = self.generator.pack_input(rn['rendered_img'], masked_img)      # cat + NCHW->NHWC fused
+            out['reconstructed_img'] = self.generator.forward_nhwc(x)
+        return out
+
+
+class OutputGatherer:
+    """All-gather of per-rank outputs with equal shard sizes (RCCL on GPUs, gloo in the CPU tests).
+
+    `start()` enqueues the collectives asynchronously into preallocated [world*n, ...] buffers and returns; `wait()` blocks
+    until the previous start() has landed.  Typical loop:  out = pipe(x); g.wait(); g.start(out)  — the gather of batch i
+    overlaps the compute of batch i+1."""
+
+    KEYS = ('vertices', 'rendered_img', 'reconstructed_img')
+
+    def __init__(self, keys=KEYS, group=None):
+        self.keys, self.group = tuple(keys), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bufs, self.pending, self._hold = {}, [], None
+
+    def start(self, outputs):
+        self._hold = {k: outputs[k].contiguous() for k in self.keys if k in outputs}
+        if self.world == 1:
+            self.bufs = dict(self._hold)
+            return
+        for k, t in self._hold.items():
+            shape = (self.world * t.shape[0],) + tuple(t.shape[1:])
+            if k not in self.bufs or self.bufs[k].shape != shape or self.bufs[k].device != t.device:
+                self.bufs[k] = torch.empty(shape, dtype=t.dtype, device=t.device)
+            self.pending.append(dist.all_gather_into_tensor(self.bufs[k], t, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        return self.bufs

@@ -133,7 +133,8 @@ class MobileNetV3Features(nn.Module):
         d.act, d.out_mode = (L.ACT_RELU if relu else L.ACT_NONE), L.OUT_NHWC
         out = torch.empty(B, H, W, w.shape[0], device=x.device)
         P = L.ptr
-        L.check(lib.smirk_conv_igemm_f32(d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st))
+        L.timed(L.igemm_kernel_name(w.shape[0]), 2.0 * B * H * W * w.shape[0] * C, lambda: L.check(lib.smirk_conv_igemm_f32(
+            d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st)))
         return out
 
     @staticmethod

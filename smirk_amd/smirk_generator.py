@@ -116,8 +116,11 @@ class SmirkGenerator(nn.Module):
         d.out_mode = L.OUT_CONVT2X2 if convt else L.OUT_NHWC
         out = torch.empty((B, 2 * H, 2 * W, cout) if convt else (B, H, W, cout), device=x0.device)
         P = L.ptr
-        L.check(lib.smirk_conv_igemm_f32(d, P(x0), P(x1, allow_none=True), P(w), P(scale, allow_none=True),
-                                         P(shift, allow_none=True), P(residual, allow_none=True), P(out), st))
+        n_gemm = 4 * cout if convt else cout
+        flops = 2.0 * B * H * W * n_gemm * (k * k * (d.C0 + d.C1))
+        L.timed(L.igemm_kernel_name(n_gemm), flops, lambda: L.check(lib.smirk_conv_igemm_f32(
+            d, P(x0), P(x1, allow_none=True), P(w), P(scale, allow_none=True), P(shift, allow_none=True),
+            P(residual, allow_none=True), P(out), st)))
         return out
 
     def forward_nhwc(self, x_nhwc, taps=None):
