@@ -56,7 +56,9 @@ def cpu_baseline(sandbox, n_faces):
     from oracle.flame_ref import FlameRef
     from oracle.render_ref import RendererRef
     from smirk_amd import synth
-    torch.set_num_threads(os.cpu_count())
+    nthr = min(os.cpu_count(), 32)          # more threads than this only thrash on a 4-16 frame sample
+    torch.set_num_threads(nthr)
+    os.environ["OMP_NUM_THREADS"] = str(nthr)
     encr = M.SmirkEncoderRef().eval()
     with torch.no_grad():
         encr.shape_encoder.shape_layers[0].weight.normal_(0, 1e-3)
@@ -65,21 +67,30 @@ def cpu_baseline(sandbox, n_faces):
     img = synth.synth_images(n_faces, seed=5)
     masked = synth.synth_generator_input(n_faces, seed=5)[:, 3:]
 
+    stages = {}
+
     def run():
+        t0 = time.perf_counter()
         with torch.no_grad():
             e = encr(img)
+        t1 = time.perf_counter()
         p = {k: v.numpy() for k, v in e.items()}
         p["cam"] = np.clip(p["cam"], [6, -.1, -.1], [10, .1, .1]).astype(np.float32)
         fl = fr.forward(p)
+        t2 = time.perf_counter()
         r = rr.forward(fl["vertices"], p["cam"])
+        t3 = time.perf_counter()
         x = torch.cat([torch.from_numpy(r["rendered_img"]), masked], 1)
-        return G.forward(gsd, x)
+        y = G.forward(gsd, x)
+        t4 = time.perf_counter()
+        stages.update(encode=t1 - t0, flame=t2 - t1, render=t3 - t2, generate=t4 - t3)
+        return y
 
     run()                                   # warm-up (also builds raster_ref.c if needed)
     t = time.perf_counter()
     run()
     dt = time.perf_counter() - t
-    return n_faces / dt, dt
+    return n_faces / dt, dt, nthr, {k: round(v, 3) for k, v in stages.items()}
 
 
 def main():
@@ -88,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
-    ap.add_argument("--cpu-faces", type=int, default=16, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-faces", type=int, default=96, help="sample size of the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -161,10 +172,11 @@ def main():
         value = faces / dt
         cpu = None
         if world == 1 and args.cpu_faces > 0:
-            v, cdt = cpu_baseline(sandbox, args.cpu_faces)
-            cpu = {"value": v, "unit": "faces/sec", "cores": os.cpu_count(), "kind": "port",
-                   "sample": f"{args.cpu_faces} synthetic 224x224 frames through the CPU oracle (torch-CPU fp32 encoder+generator on "
-                             f"{os.cpu_count()} threads, numpy FLAME, C rasteriser with OpenMP), 1 warm-up + 1 timed pass = {cdt:.1f} s"}
+            v, cdt, nthr, stages = cpu_baseline(sandbox, args.cpu_faces)
+            cpu = {"value": v, "unit": "faces/sec", "cores": nthr, "kind": "port", "host_cores": os.cpu_count(),
+                   "stage_seconds": stages,
+                   "sample": f"{args.cpu_faces} synthetic 224x224 frames through the CPU oracle (torch-CPU fp32 encoder+generator, numpy "
+                             f"FLAME, C rasteriser with OpenMP; {nthr} threads), 1 warm-up + 1 timed pass = {cdt:.1f} s"}
         print(json.dumps({
             "metric": "faces/sec (encode+FLAME+render+generate) @224x224", "value": value, "unit": "faces/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
