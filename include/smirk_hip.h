@@ -148,6 +148,23 @@ typedef struct SmirkConvDesc {
 int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* in1, const float* w,
                          const float* scale, const float* shift, const float* residual, float* out, void* stream);
 
+/* Split-fp16 arithmetic mode ("f16x3"): CDNA4 has no TF32, so fp32-class accuracy on the 16-bit matrix pipe is obtained by carrying each
+ * value as an fp16 pair x = hi + lo * 2^-11 and issuing 3 fp16 MFMAs per product block with fp32 accumulation (conv.hip header).
+ * A "split16" tensor is NHWC with each group of 8 channels stored as 8 hi halves followed by 8 lo halves: [B][H][W][C/8][2][8] fp16 —
+ * 4 bytes per element like fp32.  Same descriptor and semantics as smirk_conv_igemm_f32; in0 / in1 / residual / out are split16 tensors,
+ * w is [N][K/8][2][8] halves (K ordered (ky,kx,c)), scale / shift stay fp32.  C0, C1, Cout must be multiples of 8. */
+int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
+                           const float* scale, const float* shift, const void* residual, void* out, void* stream);
+/* fp32 <-> split16 conversion of n_elems values (n_elems % 8 == 0; groups of 8 consecutive values). */
+int smirk_f32_to_split16(const float* in, void* out, size_t n_elems, void* stream);
+int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, void* stream);
+/* split16 versions of the generator's streaming ops (smirk_generator.py:13-19,47-49,76; smirk_trainer.py:94): max-pool, fused
+ * cat(a[B,Ca,H,W], b[B,Cb,H,W]) + NCHW->NHWC + split (Ca+Cb <= 8, zero-padded to one 8-channel group), final 1x1 conv + sigmoid. */
+int smirk_maxpool2x2_split16(const void* in, void* out, int B, int H, int W, int C, void* stream);
+int smirk_pack_generator_input_split16(const float* a, int Ca, const float* b, int Cb, void* out, int B, int H, int W, void* stream);
+int smirk_conv1x1_sigmoid_nchw_split16(const void* in, const float* w /*[Cout][C] fp32*/, const float* bias, float* out,
+                                       int B, int H, int W, int C, int Cout, void* stream);
+
 /* 2x2/2 max pool, NHWC, C % 4 == 0 (smirk_generator.py:13-19). */
 int smirk_maxpool2x2_nhwc(const float* in, float* out, int B, int H, int W, int C, void* stream);
 /* NCHW [B,Cin,H,W] -> NHWC [B,H,W,Cpad] with zero-filled channels Cin..Cpad-1 (generator input pack). */

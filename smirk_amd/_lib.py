@@ -50,6 +50,12 @@ _SIGS = {
     "smirk_render_forward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_project_landmarks": (_i, [_p, _p, _i, _i, _p, _p]),
     "smirk_conv_igemm_f32": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "smirk_conv_igemm_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "smirk_f32_to_split16": (_i, [_p, _p, _sz, _p]),
+    "smirk_split16_to_f32": (_i, [_p, _p, _sz, _p]),
+    "smirk_maxpool2x2_split16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "smirk_pack_generator_input_split16": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _p]),
+    "smirk_conv1x1_sigmoid_nchw_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_maxpool2x2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "smirk_nchw_to_nhwc_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_pack_generator_input": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -131,10 +137,10 @@ def timed(kernel, flops, fn):
     return r
 
 
-def igemm_kernel_name(n_gemm):
-    """Which conv_igemm_kernel instantiation smirk_conv_igemm_f32 dispatches for a GEMM N (mirrors conv.hip)."""
-    return "conv_igemm_kernel<128,128,2,2>" if n_gemm > 64 else "conv_igemm_kernel<128,64,2,2>" if n_gemm > 32 \
-        else "conv_igemm_kernel<256,32,4,1>"
+def igemm_kernel_name(n_gemm, split=False):
+    """Which conv_igemm_kernel instantiation smirk_conv_igemm_{f32,f16x3} dispatches for a GEMM N (mirrors conv.hip)."""
+    t = "128,128,2,2" if n_gemm > 64 else "128,64,2,2" if n_gemm > 32 else "256,32,4,1"
+    return f"conv_igemm_kernel<{t},{'true' if split else 'false'}>"
 
 
 class Workspace:

@@ -1,28 +1,40 @@
-// fp32 implicit-GEMM convolution for MI355X (gfx950) on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: an exact,
-// k-ordered fp32 FMA chain at the 157 TFLOP/s matrix rate — there is no TF32 on CDNA4 and none is emulated here).
+// Implicit-GEMM convolution for MI355X (gfx950) on the matrix cores, two arithmetic modes sharing one loader:
+//
+//   F32    v_mfma_f32_32x32x2_f32 — an exact, k-ordered fp32 FMA chain at the 157 TFLOP/s f32 matrix rate.
+//   F16X3  "split-fp16": CDNA4 has no TF32, so fp32-class accuracy is obtained on the 2.5 PFLOP/s 16-bit pipe by carrying
+//          every value as an fp16 pair  x = hi + lo * 2^-11  (hi = fp16(x), lo = fp16((x - hi) * 2^11); 22 significand bits)
+//          and issuing three v_mfma_f32_32x32x16_f16 per product block:  acc0 += a_hi.w_hi ;  acc1 += a_hi.w_lo + a_lo.w_hi ;
+//          result = acc0 + acc1 * 2^-11  (fp16 x fp16 products are exact in fp32; only the 2^-22 lo.lo term is dropped).
+//          Measured error vs fp64 equals that of an fp32 GEMM.  Activations live in HBM already split:
+//          [B][H][W][C/8][2][8] halves = 4 bytes per element, the same footprint and the same 16-byte vector geometry as fp32
+//          NHWC, so the loader is shared verbatim; the epilogue re-splits its outputs.
 //
 // GEMM view:  out[m][n] = sum_k A[m][k] * Wt[n][k]
 //     m = (b, oy, ox) output pixel (NHWC), n = output channel, k = (ky, kx, c) — c contiguous, matching NHWC activations, so an
 //     im2col row segment is a contiguous run of channels and every global access is a 16-byte vector.
 // * A is gathered on the fly (zero or REFLECT padding = index arithmetic, no padded copy; a channel-concatenated input is two
 //   source tensors, so torch.cat((up, skip), 1) of the U-Net decoder is never materialised).
-// * Block tile BM x BN x 32, 4 waves; both operands are staged K-contiguous in LDS with a 36-float row stride so one
-//   ds_read_b128 per lane feeds FOUR MFMAs: lanes 0-31 take k = 4t..4t+3 and lanes 32-63 take k = 4t+4..4t+7 of each 8-k
-//   group (the MFMA's two k slots per instruction are fed the same permutation on A and B, so the sum is unchanged).
+// * Block tile BM x BN x 32, 4 waves; both operands are staged K-contiguous in LDS with a 36-dword row stride (the 16-lane
+//   groups of ds_read_b128 hit 16 distinct 16-byte slots).  F32: one ds_read_b128 per lane feeds FOUR MFMAs — lanes 0-31 take
+//   k = 4t..4t+3 and lanes 32-63 k = 4t+4..4t+7 of each 8-k group (the same permutation on A and B leaves the sum unchanged).
+//   F16X3: a lane's 16-byte read is the 8 hi (or 8 lo) halves of one 8-channel group = one MFMA operand.
 // * Next K chunk is prefetched into registers while the current one is consumed from LDS.
-// * Epilogue fuses BatchNorm(eval) scale/shift, residual add, ReLU, and (for ConvTranspose2d k2 s2) the 2x2 pixel scatter.
+// * Epilogue fuses BatchNorm(eval) scale/shift, residual add, ReLU, and (for ConvTranspose2d k2 s2) the 2x2 pixel scatter; the
+//   F16X3 epilogue transposes each wave's tile through LDS so every lane stores whole 8-channel groups (2 x 16 bytes).
 // * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous run of tiles, so blocks that share an A row
 //   panel or a weight panel hit the same private L2.
 //
-// Bound: MFMA fp32.  Algorithmic flop = 2*M*N*K.
+// Bound: MFMA (fp32 157.3 TF; f16 2.5 PF issuing 3 MFMA-flop per algorithmic flop).  Algorithmic flop = 2*M*N*K.
 #include "common.h"
 
 #define CV_BK 32
 #define CV_LDS (CV_BK + 4)
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
 struct ConvArgs {
     SmirkConvDesc d;
-    const float *in0, *in1, *w, *scale, *shift, *residual;
+    const float *in0, *in1, *w, *scale, *shift, *residual;   // F16X3: in0/in1/w/residual/out are split-fp16 tensors viewed as dwords
     float* out;
     int M, N, K, Cin;
 };
@@ -32,10 +44,23 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return (i >= n) ? (2 * n - 2 - i) : i;
 }
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// 8 fp32 values -> split-fp16 group: out_hi = fp16(v), out_lo = fp16((v - hi) * 2^11)
+__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const _Float16 h = (_Float16)v[q];
+        hi[q] = h;
+        lo[q] = (_Float16)((v[q] - (float)h) * 2048.0f);
+    }
+}
+__device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
+
+template <int BM, int BN, int WGM, int WGN, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (F16X3 epilogue)
+    static_assert(!SPLIT || 4 * 32 * EPI_LD <= (BM + BN) * CV_LDS, "epilogue buffer must fit in the operand LDS");
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CV_LDS];
     float* As = smem;
     float* Bs = smem + BM * CV_LDS;
@@ -100,13 +125,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     };
 
-    f32x16 acc[TM][TN];
+    constexpr int NACC = SPLIT ? 2 : 1;
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
     const int nchunk = (a.K + CV_BK - 1) / CV_BK;
     const int fr = lane & 31, kh = (lane >> 5) * 4;
@@ -119,73 +147,160 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int p = 0; p < PB; ++p) *(f32x4*)(Bs + (srow + 32 * p) * CV_LDS + col4 * 4) = rb[p];
         __syncthreads();
         if (ch + 1 < nchunk) load_chunk((ch + 1) * CV_BK);
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int kk = 0; kk < CV_BK / 8; ++kk) {
-            f32x4 fa[TM], fb[TN];
+            for (int s = 0; s < CV_BK / 16; ++s) {               // one 16-k MFMA step: lanes 0-31 group 2s, lanes 32-63 group 2s+1
+                const int go = (2 * s) * 8 + 2 * kh;               // dword offset of this lane's 8-channel group (kh = 0 or 4)
+                half8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(As + ((wm * TM + i) * 32 + fr) * CV_LDS + kk * 8 + kh);
+                for (int i = 0; i < TM; ++i) {
+                    const float* p = As + ((wm * TM + i) * 32 + fr) * CV_LDS + go;
+                    ah[i] = *(const half8*)p; al[i] = *(const half8*)(p + 4);
+                }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(Bs + ((wn * TN + j) * 32 + fr) * CV_LDS + kk * 8 + kh);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int j = 0; j < TN; ++j) {
+                    const float* p = Bs + ((wn * TN + j) * 32 + fr) * CV_LDS + go;
+                    bh[j] = *(const half8*)p; bl[j] = *(const half8*)(p + 4);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[0][i][j], 0, 0, 0);
+                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[NACC - 1][i][j], 0, 0, 0);
+                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[NACC - 1][i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < CV_BK / 8; ++kk) {
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(As + ((wm * TM + i) * 32 + fr) * CV_LDS + kk * 8 + kh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(Bs + ((wn * TN + j) * 32 + fr) * CV_LDS + kk * 8 + kh);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[0][i][j], 0, 0, 0);
+            }
         }
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------
     const bool convt = d.out_mode == SMIRK_OUT_CONVT2X2;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + fr;
-        if (n >= a.N) continue;
-        const int co = convt ? n % d.Cout : n;
-        const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
-        int dy = 0, dx = 0;
-        if (convt) { const int q = n / d.Cout; dy = q >> 1; dx = q & 1; }
+    if constexpr (SPLIT) {
+        __syncthreads();                                          // every wave is done with As/Bs: reuse as transpose buffers
+        float* ebuf = smem + wave * 32 * EPI_LD;
+        constexpr int GPR = TN * 4;                               // 8-channel groups per buffer row
+        constexpr int ITEMS = 32 * GPR / 64;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, lane);
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] * sc + sh;
-                size_t o;
-                if (convt) {
-                    const int b = m / HoWo, rem = m - b * HoWo;
-                    const int y = rem / d.Wo, x = rem - y * d.Wo;
-                    o = (((size_t)b * 2 * d.Ho + 2 * y + dy) * 2 * d.Wo + 2 * x + dx) * d.Cout + co;
-                } else {
-                    o = (size_t)m * d.Cout + n;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc[0][i][j][r] + acc[NACC - 1][i][j][r] * (1.0f / 2048.0f);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = it * 64 + lane, row = item / GPR, g = item % GPR;
+                const int m = m0 + (wm * TM + i) * 32 + row, n = n0 + wn * TN * 32 + g * 8;
+                if (m < a.M && n < a.N) {
+                    float v[8];
+                    *(f32x4*)v = *(const f32x4*)(ebuf + row * EPI_LD + g * 8);
+                    *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * EPI_LD + g * 8 + 4);
+                    const int co = convt ? n % d.Cout : n;
+                    size_t o;
+                    if (convt) {
+                        const int q = n / d.Cout, dy = q >> 1, dx = q & 1;
+                        const int b = m / HoWo, rem = m - b * HoWo;
+                        const int y = rem / d.Wo, x = rem - y * d.Wo;
+                        o = (((size_t)b * 2 * d.Ho + 2 * y + dy) * 2 * d.Wo + 2 * x + dx) * d.Cout + co;
+                    } else {
+                        o = (size_t)m * d.Cout + n;
+                    }
+                    if (a.scale) {
+                        const f32x4 s0 = *(const f32x4*)(a.scale + co), s1 = *(const f32x4*)(a.scale + co + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+                    }
+                    if (a.shift) {
+                        const f32x4 s0 = *(const f32x4*)(a.shift + co), s1 = *(const f32x4*)(a.shift + co + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
+                    }
+                    if (a.residual) {
+                        const half8 rh = *(const half8*)(a.residual + o), rl = *(const half8*)(a.residual + o + 4);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += join1(rh[q], rl[q]);
+                    }
+                    if (d.act == SMIRK_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    half8 hi, lo;
+                    split8(v, hi, lo);
+                    *(half8*)(a.out + o) = hi;
+                    *(half8*)(a.out + o + 4) = lo;
                 }
-                if (a.residual) v += a.residual[o];
-                if (d.act == SMIRK_ACT_RELU) v = fmaxf(v, 0.f);
-                a.out[o] = v;
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + fr;
+            if (n >= a.N) continue;
+            const int co = convt ? n % d.Cout : n;
+            const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
+            int dy = 0, dx = 0;
+            if (convt) { const int q = n / d.Cout; dy = q >> 1; dx = q & 1; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, lane);
+                    if (m >= a.M) continue;
+                    float v = acc[0][i][j][r] * sc + sh;
+                    size_t o;
+                    if (convt) {
+                        const int b = m / HoWo, rem = m - b * HoWo;
+                        const int y = rem / d.Wo, x = rem - y * d.Wo;
+                        o = (((size_t)b * 2 * d.Ho + 2 * y + dy) * 2 * d.Wo + 2 * x + dx) * d.Cout + co;
+                    } else {
+                        o = (size_t)m * d.Cout + n;
+                    }
+                    if (a.residual) v += a.residual[o];
+                    if (d.act == SMIRK_ACT_RELU) v = fmaxf(v, 0.f);
+                    a.out[o] = v;
+                }
             }
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT>
 static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), dim3(ntm * ntn), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT>), dim3(ntm * ntn), dim3(256), 0, st, a);
 }
 
-extern "C" int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* in1, const float* w,
-                                    const float* scale, const float* shift, const float* residual, float* out,
-                                    void* stream) {
+static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                         const float* shift, const void* residual, void* out, void* stream, bool split) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
-    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->C0 <= 0 || d->C0 % 4 || d->C1 % 4 || d->C1 < 0 ||
-        (d->C1 > 0 && !in1) || d->Ho <= 0 || d->Wo <= 0 || d->stride <= 0)
+    const int cq = split ? 8 : 4;                               // channel granule: one 16-byte vector (fp32) / one hi+lo group
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->C0 <= 0 || d->C0 % cq || d->C1 % cq || d->C1 < 0 ||
+        (d->C1 > 0 && !in1) || d->Ho <= 0 || d->Wo <= 0 || d->stride <= 0 || (split && d->Cout % 8))
         return SMIRK_ERR_BAD_ARG;
     if (!((d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 1))) return SMIRK_ERR_UNSUPPORTED;
     if (d->pad_mode == SMIRK_PAD_REFLECT && (d->H < 2 || d->W < 2 || d->pad_t > 1 || d->pad_l > 1)) return SMIRK_ERR_UNSUPPORTED;
     ConvArgs a;
-    a.d = *d; a.in0 = in0; a.in1 = in1; a.w = w; a.scale = scale; a.shift = shift; a.residual = residual; a.out = out;
+    a.d = *d; a.in0 = (const float*)in0; a.in1 = (const float*)in1; a.w = (const float*)w; a.scale = scale; a.shift = shift;
+    a.residual = (const float*)residual; a.out = (float*)out;
     a.Cin = d->C0 + d->C1;
     a.K = d->KH * d->KW * a.Cin;
     a.N = d->Cout;
@@ -197,9 +312,169 @@ extern "C" int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, co
     if (M > (1ll << 30) || (long long)d->B * d->H * d->W > (1ll << 30)) return SMIRK_ERR_UNSUPPORTED;
     a.M = (int)M;
     hipStream_t st = (hipStream_t)stream;
-    if (a.N > 64) launch_igemm<128, 128, 2, 2>(a, st);
-    else if (a.N > 32) launch_igemm<128, 64, 2, 2>(a, st);
-    else launch_igemm<256, 32, 4, 1>(a, st);
+    if (split) {
+        if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
+        else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
+        else launch_igemm<256, 32, 4, 1, true>(a, st);
+    } else {
+        if (a.N > 64) launch_igemm<128, 128, 2, 2, false>(a, st);
+        else if (a.N > 32) launch_igemm<128, 64, 2, 2, false>(a, st);
+        else launch_igemm<256, 32, 4, 1, false>(a, st);
+    }
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* in1, const float* w,
+                                    const float* scale, const float* shift, const float* residual, float* out,
+                                    void* stream) {
+    return conv_dispatch(d, in0, in1, w, scale, shift, residual, out, stream, false);
+}
+
+extern "C" int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
+                                      const float* scale, const float* shift, const void* residual, void* out,
+                                      void* stream) {
+    return conv_dispatch(d, in0, in1, w, scale, shift, residual, out, stream, true);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// split-fp16 companions: conversion, pooling, generator input pack, final 1x1 + sigmoid
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 [n_groups][8] -> split [n_groups][2][8] halves (and back)
+__global__ __launch_bounds__(256) void f32_to_split16_kernel(const float* __restrict__ in, float* __restrict__ out, size_t ng) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8];
+        *(f32x4*)v = *(const f32x4*)(in + i * 8);
+        *(f32x4*)(v + 4) = *(const f32x4*)(in + i * 8 + 4);
+        half8 hi, lo;
+        split8(v, hi, lo);
+        *(half8*)(out + i * 8) = hi;
+        *(half8*)(out + i * 8 + 4) = lo;
+    }
+}
+__global__ __launch_bounds__(256) void split16_to_f32_kernel(const float* __restrict__ in, float* __restrict__ out, size_t ng) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += (size_t)gridDim.x * blockDim.x) {
+        const half8 hi = *(const half8*)(in + i * 8), lo = *(const half8*)(in + i * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = join1(hi[q], lo[q]);
+        *(f32x4*)(out + i * 8) = *(f32x4*)v;
+        *(f32x4*)(out + i * 8 + 4) = *(f32x4*)(v + 4);
+    }
+}
+static unsigned grid_for(size_t total, unsigned cap) { const size_t g = (total + 255) / 256; return (unsigned)(g > cap ? cap : (g ? g : 1)); }
+
+extern "C" int smirk_f32_to_split16(const float* in, void* out, size_t n_elems, void* stream) {
+    if (!in || !out || n_elems % 8) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(f32_to_split16_kernel, dim3(grid_for(n_elems / 8, 16384)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, n_elems / 8);
+    return smirk_launch_status();
+}
+extern "C" int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, void* stream) {
+    if (!in || !out || n_elems % 8) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(split16_to_f32_kernel, dim3(grid_for(n_elems / 8, 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in, out, n_elems / 8);
+    return smirk_launch_status();
+}
+
+// 2x2/2 max pool on split tensors: the winning element's (hi, lo) pair is copied unchanged (exact).
+__global__ __launch_bounds__(256) void maxpool2x2_split_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+                                                               int W, int G) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const float* p = in + ((((size_t)b * H + 2 * oy) * W + 2 * ox) * G + g) * 8;
+        const size_t dx = (size_t)G * 8, dy = (size_t)W * G * 8;
+        half8 bh = *(const half8*)p, bl = *(const half8*)(p + 4);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float* q = p + (k & 1) * dx + (k >> 1) * dy;
+            const half8 h = *(const half8*)q, l = *(const half8*)(q + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (join1(h[e], l[e]) > join1(bh[e], bl[e])) { bh[e] = h[e]; bl[e] = l[e]; }
+        }
+        *(half8*)(out + i * 8) = bh;
+        *(half8*)(out + i * 8 + 4) = bl;
+    }
+}
+
+extern "C" int smirk_maxpool2x2_split16(const void* in, void* out, int B, int H, int W, int C, void* stream) {
+    if (!in || !out || B <= 0 || H % 2 || W % 2 || C % 8 || C <= 0) return SMIRK_ERR_BAD_ARG;
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2x2_split_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in,
+                       (float*)out, B, H, W, C / 8);
+    return smirk_launch_status();
+}
+
+// two NCHW sources (Ca + Cb <= 8 channels) -> split tensor [B][H][W][1 group]: cat + layout change + split in one pass
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b2, int Cb,
+                                                         float* __restrict__ out, int B, int HW) {
+    const size_t total = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i % HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x = 0.f;
+            if (c < Ca) x = a[(b * Ca + c) * HW + p];
+            else if (c < Ca + Cb) x = b2[(b * Cb + (c - Ca)) * HW + p];
+            v[c] = x;
+        }
+        half8 hi, lo;
+        split8(v, hi, lo);
+        *(half8*)(out + i * 8) = hi;
+        *(half8*)(out + i * 8 + 4) = lo;
+    }
+}
+
+extern "C" int smirk_pack_generator_input_split16(const float* a, int Ca, const float* b, int Cb, void* out, int B, int H, int W,
+                                                  void* stream) {
+    if (!a || !out || B <= 0 || Ca <= 0 || Cb < 0 || Ca + Cb > 8 || (Cb > 0 && !b)) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for((size_t)B * H * W, 16384)), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Cb,
+                       (float*)out, B, H * W);
+    return smirk_launch_status();
+}
+
+// final 1x1 conv C -> Cout (<=4) + bias + sigmoid on a split input; NCHW fp32 out.
+__global__ __launch_bounds__(256) void conv1x1_sigmoid_split_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int B, int HW, int C, int Cout) {
+    extern __shared__ float sw[];   // [Cout][C] + [Cout]
+    for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * C + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const size_t total = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i % HW;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* src = in + i * C;
+        for (int g = 0; g < C / 8; ++g) {
+            const half8 hi = *(const half8*)(src + g * 8), lo = *(const half8*)(src + g * 8 + 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = join1(hi[k], lo[k]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < Cout) acc[o] = fmaf(v, sw[o * C + g * 8 + k], acc[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < Cout) {
+                const float z = acc[o] + sw[Cout * C + o];
+                out[(b * Cout + o) * HW + p] = 1.0f / (1.0f + expf(-z));
+            }
+    }
+}
+
+extern "C" int smirk_conv1x1_sigmoid_nchw_split16(const void* in, const float* w, const float* bias, float* out, int B, int H,
+                                                  int W, int C, int Cout, void* stream) {
+    if (!in || !w || !out || B <= 0 || C % 8 || C <= 0 || Cout <= 0 || Cout > 4) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(conv1x1_sigmoid_split_kernel, dim3(grid_for((size_t)B * H * W, 16384)), dim3(256),
+                       (size_t)(Cout * C + Cout) * 4, (hipStream_t)stream, (const float*)in, w, bias, out, B, H * W, C, Cout);
     return smirk_launch_status();
 }
 

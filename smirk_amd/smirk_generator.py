@@ -2,11 +2,17 @@
 
 The module tree only HOLDS the parameters, under exactly the reference's state_dict keys (encoder{1-4}.enc{i}conv{1,2}.weight,
 ...norm{1,2}.*, bottleneck.*, resnet_blocks.{k}.conv_block.{1,2,5,6}.*, upconv{1-4}.*, decoder{1-4}.*, conv.* — 178 keys).
-forward() runs on libsmirk_hip.so: NHWC fp32 activations, every 3x3 / transposed / 1x1 convolution on the fp32 MFMA
-implicit-GEMM kernel with BatchNorm(eval)+ReLU(+residual) fused in the epilogue, reflection padding and the decoder's
-channel concat done as address arithmetic, 2x2 max-pool and the final 1x1+sigmoid as vectorised streaming kernels.
+forward() runs on libsmirk_hip.so: NHWC activations, every 3x3 / transposed convolution on the MFMA implicit-GEMM kernel with
+BatchNorm(eval)+ReLU(+residual) fused in the epilogue, reflection padding and the decoder's channel concat done as address
+arithmetic, 2x2 max-pool and the final 1x1+sigmoid as vectorised streaming kernels.
+
+Two arithmetic modes (`SmirkGenerator.precision`, default from $SMIRK_AMD_GENERATOR_PRECISION or "f16x3"):
+  "f16x3"  split-fp16: activations/weights carried as fp16 (hi, lo) pairs, 3 fp16 MFMAs per product with fp32 accumulation —
+           fp32-class accuracy (same error vs fp64 as an fp32 GEMM) at the 16-bit matrix rate; CDNA4 has no TF32.
+  "f32"    exact fp32 FMA chain on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
 Eval mode only this round (the cycle-path training step is BASELINE config 5 / SURVEY.md §7 step 7).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -40,6 +46,22 @@ def _bn_affine(bn):
     return scale.contiguous(), (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
 
 
+def _split16(w):
+    """fp32 [N][K] (K % 8 == 0) -> split-fp16 [N][K/8][2][8] halves, returned as a float32-typed buffer of the same byte size."""
+    n, k = w.shape
+    g = w.reshape(n, k // 8, 8)
+    hi = g.half()
+    lo = ((g - hi.float()) * 2048.0).half()
+    return torch.stack([hi, lo], 2).contiguous().view(torch.float32).reshape(n, k)
+
+
+def split16_to_float(t):
+    """split16 activation [B,H,W,C] (float32-typed storage) -> fp32 NHWC values (test / debugging helper)."""
+    B, H, W, C = t.shape
+    h = t.view(torch.float16).reshape(B, H, W, C // 8, 2, 8).float()
+    return (h[..., 0, :] + h[..., 1, :] / 2048.0).reshape(B, H, W, C)
+
+
 def _pack3x3(w, cin_pad=None):
     """[Cout,Cin,3,3] -> [Cout][(ky,kx,c)] with optional zero channel padding."""
     w = w.detach().float()
@@ -67,17 +89,24 @@ class SmirkGenerator(nn.Module):
         if f % 4 or out_channels > 4:
             raise L.SmirkHipError("gfx950 generator kernels need init_features % 4 == 0 and out_channels <= 4")
         self._packed, self._packed_key = None, None
+        self.precision = os.environ.get("SMIRK_AMD_GENERATOR_PRECISION", "f16x3")
 
     # ---- weight packing (device-side, cached until a parameter changes) ---------------------------------------------------
     def _key(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        return (self.precision,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def _pack(self):
         key = self._key()
         if self._packed is not None and self._packed_key == key:
             return self._packed
+        if self.precision not in ("f16x3", "f32"):
+            raise L.SmirkHipError(f"unknown SmirkGenerator.precision {self.precision!r}")
+        split = self.precision == "f16x3"
+        if split and (self.features % 8 or self.in_channels > 8):
+            raise L.SmirkHipError("f16x3 mode needs init_features % 8 == 0 and in_channels <= 8")
         P = {}
-        self._cin_pad = (self.in_channels + 3) // 4 * 4          # 6 -> 8: keeps every im2col access a 16-byte vector
+        # 6 -> 8 input channels: keeps every im2col access a 16-byte vector / one split-fp16 group
+        self._cin_pad = 8 if split else (self.in_channels + 3) // 4 * 4
 
         def block(seq, tag, first_pad=None):
             m = dict(seq.named_children())
@@ -96,14 +125,16 @@ class SmirkGenerator(nn.Module):
             P[f"up{lvl}"] = (w.permute(2, 3, 1, 0).reshape(4 * w.shape[1], w.shape[0]).contiguous(), None,
                              up.bias.detach().float().contiguous())
             block(getattr(self, f"decoder{lvl}"), f"dec{lvl}")
+        if split:
+            P = {k: (_split16(v[0]),) + tuple(v[1:]) for k, v in P.items()}
         P["final"] = (self.conv.weight.detach().float().reshape(self.out_channels, self.features).contiguous(), None,
                       self.conv.bias.detach().float().contiguous())
+        self._split = split
         self._packed, self._packed_key = P, key
         return P
 
     # ---- kernel calls ---------------------------------------------------------------------------------------------
-    @staticmethod
-    def _conv(lib, st, x0, x1, pk, B, H, W, cout, k=3, reflect=False, relu=True, residual=None, convt=False):
+    def _conv(self, lib, st, x0, x1, pk, B, H, W, cout, k=3, reflect=False, relu=True, residual=None, convt=False):
         w, scale, shift = pk
         d = L.SmirkConvDesc()
         d.B, d.H, d.W = B, H, W
@@ -118,13 +149,15 @@ class SmirkGenerator(nn.Module):
         P = L.ptr
         n_gemm = 4 * cout if convt else cout
         flops = 2.0 * B * H * W * n_gemm * (k * k * (d.C0 + d.C1))
-        L.timed(L.igemm_kernel_name(n_gemm), flops, lambda: L.check(lib.smirk_conv_igemm_f32(
+        fn = lib.smirk_conv_igemm_f16x3 if self._split else lib.smirk_conv_igemm_f32
+        L.timed(L.igemm_kernel_name(n_gemm, self._split), flops, lambda: L.check(fn(
             d, P(x0), P(x1, allow_none=True), P(w), P(scale, allow_none=True), P(shift, allow_none=True),
             P(residual, allow_none=True), P(out), st)))
         return out
 
     def forward_nhwc(self, x_nhwc, taps=None):
-        """x_nhwc [B,H,W,Cpad] fp32 (channels >= in_channels zero) -> [B,out_channels,H,W] sigmoid image."""
+        """x_nhwc [B,H,W,Cpad] (fp32 NHWC in "f32" mode, split16 in "f16x3" mode; channels >= in_channels zero)
+        -> [B,out_channels,H,W] fp32 sigmoid image.  `taps` collects intermediate activations in the mode's storage format."""
         if self.training:
             raise NotImplementedError("smirk_amd.SmirkGenerator implements the eval-mode forward only (call .eval())")
         lib, st, P = L.lib(), L.stream_ptr(), self._pack()
@@ -140,7 +173,7 @@ class SmirkGenerator(nn.Module):
 
         def pool(x, h, w, c):
             o = torch.empty(B, h // 2, w // 2, c, device=x.device)
-            L.check(lib.smirk_maxpool2x2_nhwc(L.ptr(x), L.ptr(o), B, h, w, c, st))
+            L.check((lib.smirk_maxpool2x2_split16 if self._split else lib.smirk_maxpool2x2_nhwc)(L.ptr(x), L.ptr(o), B, h, w, c, st))
             return o
 
         e1 = dconv(x_nhwc, None, "enc1", H, W, f); t["enc1"] = e1
@@ -160,7 +193,8 @@ class SmirkGenerator(nn.Module):
             t[f"dec{lvl}"] = d
         out = torch.empty(B, self.out_channels, H, W, device=d.device)
         wf, _, bf = P["final"]
-        L.check(lib.smirk_conv1x1_sigmoid_nchw(L.ptr(d), L.ptr(wf), L.ptr(bf), L.ptr(out), B, H, W, f, self.out_channels, st))
+        fin = lib.smirk_conv1x1_sigmoid_nchw_split16 if self._split else lib.smirk_conv1x1_sigmoid_nchw
+        L.check(fin(L.ptr(d), L.ptr(wf), L.ptr(bf), L.ptr(out), B, H, W, f, self.out_channels, st))
         return out
 
     def pack_input(self, rendered, masked):
@@ -171,7 +205,10 @@ class SmirkGenerator(nn.Module):
         if self._cin_pad != 8 or rendered.shape[1] != 3 or masked.shape[1] != 3:
             raise L.SmirkHipError("pack_input is the 3+3 channel case (SmirkGenerator(in_channels=6, ...))")
         x = torch.empty(B, H, W, 8, device=rendered.device)
-        L.check(L.lib().smirk_pack_generator_input(L.ptr(rendered), L.ptr(masked), L.ptr(x), B, H, W, L.stream_ptr()))
+        if self._split:
+            L.check(L.lib().smirk_pack_generator_input_split16(L.ptr(rendered), 3, L.ptr(masked), 3, L.ptr(x), B, H, W, L.stream_ptr()))
+        else:
+            L.check(L.lib().smirk_pack_generator_input(L.ptr(rendered), L.ptr(masked), L.ptr(x), B, H, W, L.stream_ptr()))
         return x
 
     def forward(self, x, _taps=None):
@@ -182,5 +219,8 @@ class SmirkGenerator(nn.Module):
             raise L.SmirkHipError(f"expected {self.in_channels} input channels, got {C}")
         self._pack()
         xn = torch.empty(B, H, W, self._cin_pad, device=x.device)
-        L.check(L.lib().smirk_nchw_to_nhwc_pad(L.ptr(x), L.ptr(xn), B, C, H, W, self._cin_pad, L.stream_ptr()))
+        if self._split:
+            L.check(L.lib().smirk_pack_generator_input_split16(L.ptr(x), C, None, 0, L.ptr(xn), B, H, W, L.stream_ptr()))
+        else:
+            L.check(L.lib().smirk_nchw_to_nhwc_pad(L.ptr(x), L.ptr(xn), B, C, H, W, self._cin_pad, L.stream_ptr()))
         return self.forward_nhwc(xn, _taps)

@@ -15,12 +15,14 @@ OUT_TOL = 2e-5        # abs, on the sigmoid output in [0,1]
 ACT_RTOL = 2e-4       # intermediate activations, relative to the tensor's max magnitude
 
 
-@pytest.fixture(scope="module")
-def gen():
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def gen(request):
+    """both arithmetic modes must meet the SAME tolerances: split-fp16 (default) and the exact fp32 FMA-chain path"""
     from smirk_amd import SmirkGenerator
     sd = G.synth_state_dict()
     m = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
     m.load_state_dict(sd, strict=True)
+    m.precision = request.param
     return m.cuda().eval(), sd
 
 
@@ -42,7 +44,9 @@ def test_generator_layerwise_vs_oracle(gen):
     yg = m(x.cuda(), _taps=gt)
     torch.cuda.synchronize()
     for k in ("enc1", "enc2", "enc3", "enc4", "bottleneck", "res", "dec4", "dec3", "dec2", "dec1"):
-        a, b = gt[k].permute(0, 3, 1, 2).cpu(), rt[k]
+        from smirk_amd.smirk_generator import split16_to_float
+        act = split16_to_float(gt[k]) if m.precision == "f16x3" else gt[k]
+        a, b = act.permute(0, 3, 1, 2).cpu(), rt[k]
         err = (a - b).abs().max().item() / b.abs().max().item()
         assert err < ACT_RTOL, (k, err)
     assert (yg.cpu() - yr).abs().max().item() < OUT_TOL

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smirk_amd import _lib as L  # noqa: E402
 
 
-def run(B, H, C0, C1, Cout, k, convt, reflect, iters):
+def run(B, H, C0, C1, Cout, k, convt, reflect, iters, split=False):
     lib = L.lib()
     dev = torch.device("cuda")
     x0 = torch.randn(B, H, H, C0, device=dev)
@@ -31,7 +31,8 @@ def run(B, H, C0, C1, Cout, k, convt, reflect, iters):
     d.act = L.ACT_RELU
     d.out_mode = L.OUT_CONVT2X2 if convt else L.OUT_NHWC
     P = L.ptr
-    call = lambda: L.check(lib.smirk_conv_igemm_f32(d, P(x0), P(x1, allow_none=True), P(w), P(sc), P(sh), None, P(out), L.stream_ptr()))
+    fn = lib.smirk_conv_igemm_f16x3 if split else lib.smirk_conv_igemm_f32
+    call = lambda: L.check(fn(d, P(x0), P(x1, allow_none=True), P(w), P(sc), P(sh), None, P(out), L.stream_ptr()))
     call(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -40,13 +41,14 @@ def run(B, H, C0, C1, Cout, k, convt, reflect, iters):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * H * H * n * K
-    return ms, fl / ms / 1e9
+    return ms, fl / ms / 1e9          # TFLOP/s (algorithmic)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3"])
     a = ap.parse_args()
     B = a.batch
     layers = [  # name, H, C0, C1, Cout, k, convt, reflect, count in the generator
@@ -60,7 +62,7 @@ if __name__ == "__main__":
     ]
     tot_ms = tot_fl = 0.0
     for name, H, C0, C1, Cout, k, convt, refl, cnt in layers:
-        ms, tf = run(B, H, C0, C1, Cout, k, convt, refl, a.iters)
+        ms, tf = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
         tot_ms += ms * cnt; tot_fl += tf * ms * cnt
-        print(f"{name:14s} H={H:3d} Cin={C0 + C1:4d} Cout={Cout:4d} k={k} convT={convt} x{cnt:2d}: {ms:8.3f} ms  {tf / 1e3:7.2f} TFLOP/s")
-    print(f"generator igemm total: {tot_ms:.2f} ms for B={B}  ->  {tot_fl / tot_ms / 1e3:.2f} TFLOP/s average, {B / tot_ms * 1e3:.0f} faces/s bound")
+        print(f"{name:14s} H={H:3d} Cin={C0 + C1:4d} Cout={Cout:4d} k={k} convT={convt} x{cnt:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s")
+    print(f"generator igemm total: {tot_ms:.2f} ms for B={B}  ->  {tot_fl / tot_ms:.1f} TFLOP/s average, {B / tot_ms * 1e3:.0f} faces/s bound")
