@@ -14,11 +14,12 @@
 //     im2col row segment is a contiguous run of channels and every global access is a 16-byte vector.
 // * A is gathered on the fly (zero or REFLECT padding = index arithmetic, no padded copy; a channel-concatenated input is two
 //   source tensors, so torch.cat((up, skip), 1) of the U-Net decoder is never materialised).
-// * Block tile BM x BN x 32, 4 waves; both operands are staged K-contiguous in LDS with a 36-dword row stride (the 16-lane
-//   groups of ds_read_b128 hit 16 distinct 16-byte slots).  F32: one ds_read_b128 per lane feeds FOUR MFMAs — lanes 0-31 take
-//   k = 4t..4t+3 and lanes 32-63 k = 4t+4..4t+7 of each 8-k group (the same permutation on A and B leaves the sum unchanged).
-//   F16X3: a lane's 16-byte read is the 8 hi (or 8 lo) halves of one 8-channel group = one MFMA operand.
-// * Next K chunk is prefetched into registers while the current one is consumed from LDS.
+// * Block tile BM x BN x 32, 4 waves; both operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no
+//   ds_write) into a 2-stage ring: K-contiguous 128-byte rows with an XOR piece swizzle (source side + read side) so the 16-lane
+//   groups of ds_read_b128 hit 16 distinct 16-byte slots; ONE barrier per K chunk, the next chunk's DMA runs under the MFMAs.
+//   F32: one ds_read_b128 per lane feeds FOUR MFMAs — lanes 0-31 take k = 4t..4t+3 and lanes 32-63 k = 4t+4..4t+7 of each 8-k
+//   group (the same permutation on A and B leaves the sum unchanged).  F16X3: a lane's 16-byte read is the 8 hi (or 8 lo)
+//   halves of one 8-channel group = one MFMA operand.
 // * Epilogue fuses BatchNorm(eval) scale/shift, residual add, ReLU, and (for ConvTranspose2d k2 s2) the 2x2 pixel scatter; the
 //   F16X3 epilogue transposes each wave's tile through LDS so every lane stores whole 8-channel groups (2 x 16 bytes).
 // * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous run of tiles, so blocks that share an A row
@@ -28,7 +29,6 @@
 #include "common.h"
 
 #define CV_BK 32
-#define CV_LDS (CV_BK + 4)
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -37,7 +37,20 @@ struct ConvArgs {
     const float *in0, *in1, *w, *scale, *shift, *residual;   // F16X3: in0/in1/w/residual/out are split-fp16 tensors viewed as dwords
     float* out;
     int M, N, K, Cin;
+    int psh;       // GEMM rows enumerate each image in (2^psh x 2^psh)-pixel patches (tile-major): a BM-row tile is then a compact 2-D
+                   // patch whose 3x3 halo is ~1.3x its area instead of 3 full image rows — the im2col re-reads stay in L1/L2
 };
+
+// GEMM row -> (image, y, x).  Inside an image rows are ordered patch-major; any bijection is valid because every output
+// address is computed from (b, y, x).
+__device__ __forceinline__ void row_to_pixel(int m, int HoWo, int Wo, int psh, int& b, int& oy, int& ox) {
+    b = m / HoWo;
+    const int rem = m - b * HoWo;
+    const int t = rem >> (2 * psh), in = rem & ((1 << (2 * psh)) - 1);
+    const int tpr = Wo >> psh, ty = t / tpr, tx = t - ty * tpr;
+    oy = (ty << psh) + (in >> psh);
+    ox = (tx << psh) + (in & ((1 << psh) - 1));
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = (i < 0) ? -i : i;
@@ -55,15 +68,23 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 }
 __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
 
+// 16 zero bytes in global memory: the source of a direct-to-LDS load whose im2col element is padding / out of range
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// LDS operand image: [rows][32 dwords] (one 128-byte K chunk per row), written by global_load_lds_dwordx4 — 64 lanes x 16 B =
+// 8 consecutive rows per wave instruction, lane-linear, so no padding is possible.  Bank conflicts are removed by an XOR
+// swizzle applied on the SOURCE side (which 16-byte piece of the row a lane fetches) and on the read side:
+// physical piece = logical piece ^ ((row >> 1) & 7)  => the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
+
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int STAGE = (BM + BN) * 32;                       // dwords per pipeline stage
     constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (F16X3 epilogue)
-    static_assert(!SPLIT || 4 * 32 * EPI_LD <= (BM + BN) * CV_LDS, "epilogue buffer must fit in the operand LDS");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CV_LDS];
-    float* As = smem;
-    float* Bs = smem + BM * CV_LDS;
+    static_assert(!SPLIT || 4 * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -80,16 +101,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
     const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
 
-    // ---- per-thread staging coordinates -------------------------------------------------------------------------------
-    const int col4 = tid & 7, srow = tid >> 3;
+    // ---- per-thread staging coordinates: thread (srow, pos) fills LDS row srow+32p, physical piece pos ----------------------
+    const int pos = tid & 7, srow = tid >> 3;
+    const int col4 = pos ^ ((srow >> 1) & 7);                   // logical 16-byte piece this lane fetches (source-side swizzle)
     int iy0[PA], ix0[PA], boff[PA];
     const int HoWo = d.Ho * d.Wo;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const int m = m0 + srow + 32 * p;
         if (m < a.M) {
-            const int b = m / HoWo, rem = m - b * HoWo;
-            const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+            int b, oy, ox;
+            row_to_pixel(m, HoWo, d.Wo, a.psh, b, oy, ox);
             iy0[p] = oy * d.stride - d.pad_t;
             ix0[p] = ox * d.stride - d.pad_l;
             boff[p] = b * d.H * d.W;
@@ -97,8 +119,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             iy0[p] = -(1 << 28); ix0[p] = 0; boff[p] = 0;      // out of range => always zero-filled (never reflected: guarded below)
         }
     }
-    f32x4 ra[PA], rb[PB];
-    auto load_chunk = [&](int k0) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // issue the direct-to-LDS loads of K chunk k0 into pipeline stage `st` (PA + PB instructions per wave, 1 KiB each)
+    auto issue_chunk = [&](int k0, int st) {
+        float* As = smem + st * STAGE;
+        float* Bs = As + BM * 32;
         const int k = k0 + col4 * 4;
         const bool kval = k < a.K;
         int tap = 0, c = 0;
@@ -116,12 +142,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             } else {
                 ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
             }
-            ra[p] = ok ? *(const f32x4*)(src + ((size_t)(boff[p] + iy * d.W + ix) * cs + cc)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* g = ok ? src + ((size_t)(boff[p] + iy * d.W + ix) * cs + cc) : g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + 32 * p) * 32), 16, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             const int n = n0 + srow + 32 * p;
-            rb[p] = (kval && n < a.N) ? *(const f32x4*)(a.w + (size_t)n * a.K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* g = (kval && n < a.N) ? a.w + (size_t)n * a.K + k : g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + 32 * p) * 32), 16, 0, 0);
         }
     };
 
@@ -137,30 +165,85 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
     const int nchunk = (a.K + CV_BK - 1) / CV_BK;
-    const int fr = lane & 31, kh = (lane >> 5) * 4;
-    load_chunk(0);
+    const int fr = lane & 31, hb = lane >> 5;
+
+    // ---- fast K walk (every source has C % 32 == 0, i.e. all generator layers but the first): a K chunk never straddles a tap or
+    // a concat source, so the im2col pointers are set up once per (tap, source) SEGMENT and then just advance by 128 bytes per
+    // chunk; the per-chunk cost is PA+PB pointer bumps instead of a divide + bounds/reflect + 64-bit address rebuild per row.
+    const bool fastk = (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0);
+    const float* pa[PA];
+    const float* pb[PB];
+    int inca[PA];                                               // 32 dwords, or 0 when the row reads the zero page
+    int seg_left = 0, seg_tap = 0, seg_src = 0;                 // chunks left in the current segment; next segment to open
+    auto open_segment = [&]() {
+        const int ky = seg_tap / d.KW, kx = seg_tap - ky * d.KW;
+        const float* src = seg_src ? a.in1 : a.in0;
+        const int cs = seg_src ? d.C1 : d.C0;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int iy = iy0[p] + ky, ix = ix0[p] + kx;
+            bool ok = iy0[p] > -(1 << 27);
+            if (d.pad_mode == SMIRK_PAD_REFLECT) {
+                if (ok) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); }
+            } else {
+                ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            }
+            pa[p] = ok ? src + ((size_t)(boff[p] + iy * d.W + ix) * cs + col4 * 4) : g_zero16;
+            inca[p] = ok ? CV_BK : 0;
+        }
+        seg_left = cs / CV_BK;
+        if (d.C1 > 0 && seg_src == 0) seg_src = 1; else { seg_src = 0; ++seg_tap; }
+    };
+    auto issue_fast = [&](int st) {
+        float* As = smem + st * STAGE;
+        float* Bs = As + BM * 32;
+        if (seg_left == 0) open_segment();
+        --seg_left;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            __builtin_amdgcn_global_load_lds((gptr_t)pa[p], (lptr_t)(As + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            pa[p] += inca[p];
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[p], (lptr_t)(Bs + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            pb[p] += (pb[p] == g_zero16) ? 0 : CV_BK;
+        }
+    };
+    if (fastk) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int n = n0 + srow + 32 * p;
+            pb[p] = (n < a.N) ? a.w + (size_t)n * a.K + col4 * 4 : g_zero16;
+        }
+        issue_fast(0);
+    } else {
+        issue_chunk(0, 0);
+    }
     for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PA; ++p) *(f32x4*)(As + (srow + 32 * p) * CV_LDS + col4 * 4) = ra[p];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) *(f32x4*)(Bs + (srow + 32 * p) * CV_LDS + col4 * 4) = rb[p];
-        __syncthreads();
-        if (ch + 1 < nchunk) load_chunk((ch + 1) * CV_BK);
+        // chunk ch has landed in LDS once THIS wave's loads retire and every wave has passed the barrier; the barrier also means
+        // every wave finished reading stage (ch+1)&1 (used by chunk ch-1), so it may be refilled right away, under the MFMAs.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ch + 1 < nchunk) {
+            if (fastk) issue_fast((ch + 1) & 1); else issue_chunk((ch + 1) * CV_BK, (ch + 1) & 1);
+        }
+        const float* As = smem + (ch & 1) * STAGE;
+        const float* Bs = As + BM * 32;
         if constexpr (SPLIT) {
 #pragma unroll
             for (int s = 0; s < CV_BK / 16; ++s) {               // one 16-k MFMA step: lanes 0-31 group 2s, lanes 32-63 group 2s+1
-                const int go = (2 * s) * 8 + 2 * kh;               // dword offset of this lane's 8-channel group (kh = 0 or 4)
+                const int pc = 2 * (2 * s + hb);                  // logical piece of this lane's hi halves (lo = pc + 1)
                 half8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const float* p = As + ((wm * TM + i) * 32 + fr) * CV_LDS + go;
-                    ah[i] = *(const half8*)p; al[i] = *(const half8*)(p + 4);
+                    const int row = (wm * TM + i) * 32 + fr;
+                    ah[i] = *(const half8*)(As + lds_piece(row, pc)); al[i] = *(const half8*)(As + lds_piece(row, pc + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const float* p = Bs + ((wn * TN + j) * 32 + fr) * CV_LDS + go;
-                    bh[j] = *(const half8*)p; bl[j] = *(const half8*)(p + 4);
+                    const int row = (wn * TN + j) * 32 + fr;
+                    bh[j] = *(const half8*)(Bs + lds_piece(row, pc)); bl[j] = *(const half8*)(Bs + lds_piece(row, pc + 1));
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -176,9 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             for (int kk = 0; kk < CV_BK / 8; ++kk) {
                 f32x4 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(As + ((wm * TM + i) * 32 + fr) * CV_LDS + kk * 8 + kh);
+                for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4*)(As + lds_piece((wm * TM + i) * 32 + fr, kk * 2 + hb));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(Bs + ((wn * TN + j) * 32 + fr) * CV_LDS + kk * 8 + kh);
+                for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4*)(Bs + lds_piece((wn * TN + j) * 32 + fr, kk * 2 + hb));
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -215,13 +298,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * EPI_LD + g * 8 + 4);
                     const int co = convt ? n % d.Cout : n;
                     size_t o;
+                    int b, y, x;
+                    row_to_pixel(m, HoWo, d.Wo, a.psh, b, y, x);
                     if (convt) {
                         const int q = n / d.Cout, dy = q >> 1, dx = q & 1;
-                        const int b = m / HoWo, rem = m - b * HoWo;
-                        const int y = rem / d.Wo, x = rem - y * d.Wo;
                         o = (((size_t)b * 2 * d.Ho + 2 * y + dy) * 2 * d.Wo + 2 * x + dx) * d.Cout + co;
                     } else {
-                        o = (size_t)m * d.Cout + n;
+                        o = (((size_t)b * d.Ho + y) * d.Wo + x) * d.Cout + n;
                     }
                     if (a.scale) {
                         const f32x4 s0 = *(const f32x4*)(a.scale + co), s1 = *(const f32x4*)(a.scale + co + 4);
@@ -267,13 +350,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     if (m >= a.M) continue;
                     float v = acc[0][i][j][r] * sc + sh;
                     size_t o;
-                    if (convt) {
-                        const int b = m / HoWo, rem = m - b * HoWo;
-                        const int y = rem / d.Wo, x = rem - y * d.Wo;
-                        o = (((size_t)b * 2 * d.Ho + 2 * y + dy) * 2 * d.Wo + 2 * x + dx) * d.Cout + co;
-                    } else {
-                        o = (size_t)m * d.Cout + n;
-                    }
+                    int b, y, x;
+                    row_to_pixel(m, HoWo, d.Wo, a.psh, b, y, x);
+                    if (convt) o = (((size_t)b * 2 * d.Ho + 2 * y + dy) * 2 * d.Wo + 2 * x + dx) * d.Cout + co;
+                    else o = (((size_t)b * d.Ho + y) * d.Wo + x) * d.Cout + n;
                     if (a.residual) v += a.residual[o];
                     if (d.act == SMIRK_ACT_RELU) v = fmaxf(v, 0.f);
                     a.out[o] = v;
@@ -311,6 +391,9 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     const long long M = (long long)d->B * d->Ho * d->Wo;
     if (M > (1ll << 30) || (long long)d->B * d->H * d->W > (1ll << 30)) return SMIRK_ERR_UNSUPPORTED;
     a.M = (int)M;
+    a.psh = 0;
+    if (d->KH == 3)                                             // only convs with a halo profit from patch ordering
+        while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
     hipStream_t st = (hipStream_t)stream;
     if (split) {
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);

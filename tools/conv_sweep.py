@@ -49,6 +49,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--only", default="", help="substring filter on the layer name")
     a = ap.parse_args()
     B = a.batch
     layers = [  # name, H, C0, C1, Cout, k, convt, reflect, count in the generator
@@ -62,6 +63,8 @@ if __name__ == "__main__":
     ]
     tot_ms = tot_fl = 0.0
     for name, H, C0, C1, Cout, k, convt, refl, cnt in layers:
+        if a.only and a.only not in name:
+            continue
         ms, tf = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
         tot_ms += ms * cnt; tot_fl += tf * ms * cnt
         print(f"{name:14s} H={H:3d} Cin={C0 + C1:4d} Cout={Cout:4d} k={k} convT={convt} x{cnt:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s")
