@@ -26,6 +26,8 @@
 //   panel or a weight panel hit the same private L2.
 //
 // Bound: MFMA (fp32 157.3 TF; f16 2.5 PF issuing 3 MFMA-flop per algorithmic flop).  Algorithmic flop = 2*M*N*K.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define CV_BK 32
@@ -69,7 +71,8 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
 
 // 16 zero bytes in global memory: the source of a direct-to-LDS load whose im2col element is padding / out of range
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_zero16_conv[4] = {0.f, 0.f, 0.f, 0.f};
+#define g_zero16 g_zero16_conv
 
 // LDS operand image: [rows][32 dwords] (one 128-byte K chunk per row), written by global_load_lds_dwordx4 — 64 lanes x 16 B =
 // 8 consecutive rows per wave instruction, lane-linear, so no padding is possible.  Bank conflicts are removed by an XOR
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int PA = BM / 32, PB = BN / 32;
     constexpr int STAGE = (BM + BN) * 32;                       // dwords per pipeline stage
     constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (F16X3 epilogue)
-    static_assert(!SPLIT || 4 * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
+    static_assert(4 * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -170,11 +173,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // ---- fast K walk (every source has C % 32 == 0, i.e. all generator layers but the first): a K chunk never straddles a tap or
     // a concat source, so the im2col pointers are set up once per (tap, source) SEGMENT and then just advance by 128 bytes per
     // chunk; the per-chunk cost is PA+PB pointer bumps instead of a divide + bounds/reflect + 64-bit address rebuild per row.
-    const bool fastk = (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0);
+    // 1x1 convolutions (the encoders' pointwise layers, any C % 4 == 0) take the same path: one segment per source whose last chunk is
+    // partial — lanes whose 16-byte piece lies beyond the segment read the zero page.
+    const bool fastk = ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) || (d.KH * d.KW == 1);
     const float* pa[PA];
     const float* pb[PB];
     int inca[PA];                                               // 32 dwords, or 0 when the row reads the zero page
     int seg_left = 0, seg_tap = 0, seg_src = 0;                 // chunks left in the current segment; next segment to open
+    int kleft = 0;                                              // dwords of the segment still ahead of this lane's piece (<= 0: zero-fill)
     auto open_segment = [&]() {
         const int ky = seg_tap / d.KW, kx = seg_tap - ky * d.KW;
         const float* src = seg_src ? a.in1 : a.in0;
@@ -191,7 +197,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             pa[p] = ok ? src + ((size_t)(boff[p] + iy * d.W + ix) * cs + col4 * 4) : g_zero16;
             inca[p] = ok ? CV_BK : 0;
         }
-        seg_left = cs / CV_BK;
+        const int kbase = seg_tap * a.Cin + (seg_src ? d.C0 : 0) + col4 * 4;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int n = n0 + srow + 32 * p;
+            pb[p] = (n < a.N) ? a.w + (size_t)n * a.K + kbase : g_zero16;
+        }
+        seg_left = (cs + CV_BK - 1) / CV_BK;
+        kleft = cs - col4 * 4;
         if (d.C1 > 0 && seg_src == 0) seg_src = 1; else { seg_src = 0; ++seg_tap; }
     };
     auto issue_fast = [&](int st) {
@@ -199,33 +212,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         float* Bs = As + BM * 32;
         if (seg_left == 0) open_segment();
         --seg_left;
+        const bool kv = kleft > 0;
+        kleft -= CV_BK;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t)pa[p], (lptr_t)(As + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pa[p] : g_zero16), (lptr_t)(As + (wave * 8 + 32 * p) * 32), 16, 0, 0);
             pa[p] += inca[p];
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[p], (lptr_t)(Bs + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pb[p] : g_zero16), (lptr_t)(Bs + (wave * 8 + 32 * p) * 32), 16, 0, 0);
             pb[p] += (pb[p] == g_zero16) ? 0 : CV_BK;
         }
     };
-    if (fastk) {
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int n = n0 + srow + 32 * p;
-            pb[p] = (n < a.N) ? a.w + (size_t)n * a.K + col4 * 4 : g_zero16;
-        }
-        issue_fast(0);
-    } else {
-        issue_chunk(0, 0);
-    }
-    for (int ch = 0; ch < nchunk; ++ch) {
+    if (fastk) issue_fast(0); else issue_chunk(0, 0);
+    const int nloop = fastk ? d.KH * d.KW * ((d.C0 + CV_BK - 1) / CV_BK + (d.C1 + CV_BK - 1) / CV_BK) : nchunk;
+    for (int ch = 0; ch < nloop; ++ch) {
         // chunk ch has landed in LDS once THIS wave's loads retire and every wave has passed the barrier; the barrier also means
         // every wave finished reading stage (ch+1)&1 (used by chunk ch-1), so it may be refilled right away, under the MFMAs.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (ch + 1 < nchunk) {
+        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
+        if (ch + 1 < nloop) {
             if (fastk) issue_fast((ch + 1) & 1); else issue_chunk((ch + 1) * CV_BK, (ch + 1) & 1);
         }
         const float* As = smem + (ch & 1) * STAGE;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------
     const bool convt = d.out_mode == SMIRK_OUT_CONVT2X2;
-    if constexpr (SPLIT) {
+    if (SPLIT || (a.N % 8 == 0)) {                              // whole 8-channel groups: transpose through LDS, 2 x 16-byte stores per lane
         __syncthreads();                                          // every wave is done with As/Bs: reuse as transpose buffers
         float* ebuf = smem + wave * 32 * EPI_LD;
         constexpr int GPR = TN * 4;                               // 8-channel groups per buffer row
@@ -286,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc[0][i][j][r] + acc[NACC - 1][i][j][r] * (1.0f / 2048.0f);
+                    ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] =
+                        SPLIT ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] * (1.0f / 2048.0f) : acc[0][i][j][r];
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -317,18 +326,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                         for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
                     }
                     if (a.residual) {
-                        const half8 rh = *(const half8*)(a.residual + o), rl = *(const half8*)(a.residual + o + 4);
+                        if constexpr (SPLIT) {
+                            const half8 rh = *(const half8*)(a.residual + o), rl = *(const half8*)(a.residual + o + 4);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] += join1(rh[q], rl[q]);
+                            for (int q = 0; q < 8; ++q) v[q] += join1(rh[q], rl[q]);
+                        } else {
+                            const f32x4 r0 = *(const f32x4*)(a.residual + o), r1 = *(const f32x4*)(a.residual + o + 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+                        }
                     }
                     if (d.act == SMIRK_ACT_RELU) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                     }
-                    half8 hi, lo;
-                    split8(v, hi, lo);
-                    *(half8*)(a.out + o) = hi;
-                    *(half8*)(a.out + o + 4) = lo;
+                    if constexpr (SPLIT) {
+                        half8 hi, lo;
+                        split8(v, hi, lo);
+                        *(half8*)(a.out + o) = hi;
+                        *(half8*)(a.out + o + 4) = lo;
+                    } else {
+                        *(f32x4*)(a.out + o) = *(f32x4*)v;
+                        *(f32x4*)(a.out + o + 4) = *(f32x4*)(v + 4);
+                    }
                 }
             }
             __syncthreads();
@@ -369,6 +389,11 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT>), dim3(ntm * ntn), dim3(256), 0, st, a);
 }
 
+// conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
+bool smirk_conv3x3_patch_eligible(const SmirkConvDesc* d, bool has_residual);
+int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                               const float* shift, void* out, hipStream_t st);
+
 static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                          const float* shift, const void* residual, void* out, void* stream, bool split) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
@@ -395,6 +420,9 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     if (d->KH == 3)                                             // only convs with a halo profit from patch ordering
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
+    if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
+        return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st);
     if (split) {
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);

@@ -1,0 +1,251 @@
+// 3x3 stride-1 zero-padded convolution for LARGE images with FEW channels (the U-Net's 224x224 / 112x112 layers) on MI355X,
+// split-fp16 (f16x3) arithmetic — see conv.hip for the number format.
+//
+// For these layers an im2col GEMM is bound by operand movement, not MFMA: N = Cout is only 32-64 wide, so every input element
+// fetched into the CU feeds very few MACs and the 9 taps re-fetch it 9 times.  Here a workgroup owns a 16x16-pixel output patch:
+//   * the (16+2)x(16+2) input halo patch of one 32-channel chunk is DMA'd ONCE into LDS (global_load_lds_dwordx4, XOR piece
+//     swizzle, zero page for out-of-image halo pixels) and all 9 taps read it from there  -> 1.27x the unique bytes instead of 9x;
+//   * the layer's whole weight tensor stays resident in LDS ([chunk][tap][Cout][32 dwords], <= 72 KiB) because workgroups are
+//     PERSISTENT: 256 of them (one per CU) walk the patch list, double-buffering the next halo patch under the current MFMAs;
+//   * 4 waves x (2 M-tiles of 32 pixels) x (Cout/32 N-tiles); K = 9 taps x 32 channels per chunk = 18 MFMA k-steps of 16;
+//   * epilogue: BatchNorm(eval) scale/shift + ReLU, re-split to fp16 pairs, transposed through LDS, 32-byte stores per lane.
+// A concatenated input (decoder: up ++ skip) is two source tensors, one chunk sequence each.
+//
+// Bound: HBM (activation read 1.27x + write 1x) once the DMA is hidden; MFMA work is ~40 % of that time.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define PT 16                    // output patch edge
+#define PH (PT + 2)              // halo patch edge
+#define PPIX (PH * PH)           // 324 halo pixels
+#define PSTAGE (((PPIX + 7) / 8 * 8) * 32)   // dwords per input stage (one 32-channel chunk); whole 8-pixel DMA instructions => 328 pixels
+
+__device__ __attribute__((aligned(16))) float g_zero16_patch[4] = {0.f, 0.f, 0.f, 0.f};
+#define g_zero16 g_zero16_patch
+
+struct PatchArgs {
+    const float *in0, *in1, *w, *scale, *shift;
+    float* out;
+    int B, H, W, C0, C1, Cout;
+    int nchunk;      // 32-channel chunks per patch (over both sources)
+    int npatch;      // B * (H/16) * (W/16)
+    int act;
+};
+
+__device__ __forceinline__ int lds_piece_p(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
+
+__device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const _Float16 h = (_Float16)v[q];
+        hi[q] = h;
+        lo[q] = (_Float16)((v[q] - (float)h) * 2048.0f);
+    }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel(PatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int COUT = TN * 32;
+    constexpr int EPI_LD = COUT + 4;
+    static_assert(4 * 32 * EPI_LD <= PSTAGE, "transpose buffers must fit in one input stage");
+    float* Wl = smem;                                            // [nchunk][9][COUT][32]
+    float* St = smem + a.nchunk * 9 * COUT * 32;                 // 2 input stages
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, hb = lane >> 5;
+    const int Cin = a.C0 + a.C1, K = 9 * Cin;
+
+    // ---- weights -> LDS once: row (cc, tap, n) = 128 bytes at w[n][tap*Cin + cc*32 ...]; pieces beyond the layer's channels are zero
+    {
+        const int rows = a.nchunk * 9 * COUT;
+        for (int r0 = wave * 8; r0 < rows; r0 += 32) {
+            const int row = r0 + (lane >> 3), pos = lane & 7;
+            const int piece = pos ^ ((row >> 1) & 7);
+            const int cc = row / (9 * COUT), rem = row - cc * 9 * COUT, tap = rem / COUT, n = rem - tap * COUT;
+            const int c = cc * 32 + piece * 4;
+            const float* g = (row < rows && c < Cin) ? a.w + (size_t)n * K + tap * Cin + c : g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + r0 * 32), 16, 0, 0);
+        }
+    }
+    // ---- per-lane halo pixel slots: instruction q of this wave covers halo pixels (q*4 + wave)*8 .. +7
+    constexpr int NQ = (PPIX + 31) / 32;                         // 11 (the last one is partial)
+    int hp_y[NQ], hp_x[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pix = (q * 4 + wave) * 8 + (lane >> 3);
+        hp_y[q] = pix < PPIX ? pix / PH : -100000;
+        hp_x[q] = pix - (pix / PH) * PH;
+    }
+    const int tiles_x = a.W / PT, tiles_per_img = (a.H / PT) * tiles_x;
+    const int nitem = a.npatch * a.nchunk;
+    auto item_patch = [&](int item, int& b, int& oy0, int& ox0, int& cc) {
+        const int p = item / a.nchunk;
+        cc = item - p * a.nchunk;
+        b = p / tiles_per_img;
+        const int t = p - b * tiles_per_img;
+        oy0 = (t / tiles_x) * PT;
+        ox0 = (t - (t / tiles_x) * tiles_x) * PT;
+    };
+    auto issue_item = [&](int item, int st) {
+        int b, oy0, ox0, cc;
+        item_patch(item, b, oy0, ox0, cc);
+        const int c0 = cc * 32;
+        const bool s1 = c0 >= a.C0;
+        const float* src = s1 ? a.in1 : a.in0;
+        const int cs = s1 ? a.C1 : a.C0, cb = s1 ? c0 - a.C0 : c0;
+        float* dst = St + st * PSTAGE;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pixbase = (q * 4 + wave) * 8;
+            if (pixbase < PPIX) {                                // wave-uniform
+                const int pix = pixbase + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
+                const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (cb + piece * 4) < cs;
+                const float* g = ok ? src + ((size_t)(b * a.H + iy) * a.W + ix) * cs + cb + piece * 4 : g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + pixbase * 32), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc0[2][TN], acc1[2][TN];
+    const int ry = fr >> 4, rx = fr & 15;
+    int item = blockIdx.x * a.nchunk;                            // each block walks whole patches: items blockIdx*nchunk .. , stride grid*nchunk
+    const int stride = gridDim.x * a.nchunk;
+    auto next_item = [&](int it) { return (it % a.nchunk == a.nchunk - 1) ? it - (a.nchunk - 1) + stride : it + 1; };
+    if (item < nitem) issue_item(item, 0);
+    int st = 0;
+    while (item < nitem) {
+        int b, oy0, ox0, cc;
+        item_patch(item, b, oy0, ox0, cc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it                            // stage st (and, first time, the weights) landed; stage st^1 is free
+        const int nxt = next_item(item);
+        if (nxt < nitem) issue_item(nxt, st ^ 1);
+        if (cc == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+        }
+        const float* A = St + st * PSTAGE;
+        const float* Wc = Wl + cc * 9 * COUT * 32;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int pc = 2 * (2 * s + hb);
+                half8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pix = (4 * wave + 2 * i + ry + ky) * PH + rx + kx;
+                    ah[i] = *(const half8*)(A + lds_piece_p(pix, pc));
+                    al[i] = *(const half8*)(A + lds_piece_p(pix, pc + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = tap * COUT + j * 32 + fr;
+                    bh[j] = *(const half8*)(Wc + lds_piece_p(row, pc));
+                    bl[j] = *(const half8*)(Wc + lds_piece_p(row, pc + 1));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+            }
+        }
+        if (cc == a.nchunk - 1) {
+            // ---- epilogue: this stage's LDS is dead now (next DMA went to the other stage): use it as per-wave transpose buffers
+            __syncthreads();
+            float* ebuf = St + st * PSTAGE + wave * 32 * EPI_LD;
+            constexpr int GPR = COUT / 8, ITEMS = 32 * GPR / 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int e = it * 64 + lane, row = e / GPR, g = e % GPR;
+                    const int oy = oy0 + 4 * wave + 2 * i + (row >> 4), ox = ox0 + (row & 15);
+                    float v[8];
+                    *(f32x4*)v = *(const f32x4*)(ebuf + row * EPI_LD + g * 8);
+                    *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * EPI_LD + g * 8 + 4);
+                    if (a.scale) {
+                        const f32x4 s0 = *(const f32x4*)(a.scale + g * 8), s1 = *(const f32x4*)(a.scale + g * 8 + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+                    }
+                    if (a.shift) {
+                        const f32x4 s0 = *(const f32x4*)(a.shift + g * 8), s1 = *(const f32x4*)(a.shift + g * 8 + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
+                    }
+                    if (a.act == SMIRK_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    half8 hi, lo;
+                    split8p(v, hi, lo);
+                    float* o = a.out + (((size_t)b * a.H + oy) * a.W + ox) * COUT + g * 8;
+                    *(half8*)o = hi;
+                    *(half8*)(o + 4) = lo;
+                }
+                __syncthreads();
+            }
+        }
+        item = nxt;
+        st ^= 1;
+    }
+}
+
+// Can this layer run on the patch kernel?  (3x3, stride 1, zero pad 1, same size, H,W % 16 == 0, Cout 32/64, weights resident)
+static bool patch_eligible(const SmirkConvDesc* d, bool has_residual) {
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->pad_mode != SMIRK_PAD_ZERO) return false;
+    if (d->out_mode != SMIRK_OUT_NHWC || d->Ho != d->H || d->Wo != d->W || d->H % PT || d->W % PT || has_residual) return false;
+    if (d->Cout != 32 && d->Cout != 64) return false;
+    if (d->C1 > 0 && d->C0 % 32) return false;
+    const int nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
+    const size_t lds = ((size_t)nchunk * 9 * d->Cout * 32 + 2 * PSTAGE) * 4;
+    return lds <= 160 * 1024 && d->H >= 64;
+}
+
+int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                               const float* shift, void* out, hipStream_t st) {
+    PatchArgs a;
+    a.in0 = (const float*)in0; a.in1 = (const float*)in1; a.w = (const float*)w; a.scale = scale; a.shift = shift; a.out = (float*)out;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
+    a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
+    a.npatch = d->B * (d->H / PT) * (d->W / PT);
+    const size_t lds = ((size_t)a.nchunk * 9 * d->Cout * 32 + 2 * PSTAGE) * 4;
+    const int grid = a.npatch < 256 ? a.npatch : 256;
+    static bool attr_done[2] = {false, false};
+    if (d->Cout == 32) {
+        if (!attr_done[0]) { hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
+        hipLaunchKernelGGL(conv3x3_patch_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        if (!attr_done[1]) { hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
+        hipLaunchKernelGGL(conv3x3_patch_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+    }
+    return smirk_launch_status();
+}
+
+bool smirk_conv3x3_patch_eligible(const SmirkConvDesc* d, bool has_residual) { return patch_eligible(d, has_residual); }

@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import _lib as L
 
 BN_EPS = 1e-3   # "tf_" models
+_STREAMS = {}   # per-device side streams of SmirkEncoder.forward (kept off the module so copy.deepcopy(encoder) keeps working)
 
 _ARCH = {
     # (block type, repeats, stride, expansion, out channels); every kernel is 3x3 (1x1 for 'cn'), ReLU, no SE ("minimal")
@@ -251,8 +252,21 @@ class SmirkEncoder(nn.Module):
         self.expression_encoder = ExpressionEncoder(n_exp=n_exp)
 
     def forward(self, img):
+        """The three regressors are independent (smirk_encoder.py:123-133 runs them back to back): each gets its own HIP stream so
+        their many small launches interleave on the 256 CUs; the caller's stream joins all three before the dict is returned."""
         outputs = {}
-        outputs.update(self.pose_encoder(img))
-        outputs.update(self.shape_encoder(img))
-        outputs.update(self.expression_encoder(img))
+        if not img.is_cuda:
+            raise L.SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
+        main = torch.cuda.current_stream()
+        if img.device not in _STREAMS:
+            _STREAMS[img.device] = [torch.cuda.Stream(device=img.device) for _ in range(3)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for st, enc in zip(_STREAMS[img.device], (self.pose_encoder, self.shape_encoder, self.expression_encoder)):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                outputs.update(enc(img))
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
         return outputs
