@@ -41,6 +41,75 @@ class SmirkPipeline:
         return out
 
 
+class OverlappedPipeline:
+    """Software-pipelines consecutive, independent frame batches over two HIP streams: the latency/bandwidth-bound front
+    (encode -> FLAME -> render) of batch i+1 runs concurrently with the MFMA-bound generator of batch i, so the matrix cores and the
+    memory system are both kept busy.  Results are identical to SmirkPipeline.__call__ (same kernels, same inputs); only the
+    interleaving on the GPU changes.
+
+        run = OverlappedPipeline(pipe)
+        for img, masked in batches:
+            done = run.submit(img, masked)      # -> outputs of the PREVIOUS batch (None the first time)
+        last = run.flush()
+    """
+
+    def __init__(self, pipe):
+        self.pipe = pipe
+        self.front_stream, self.gen_stream = None, None
+        self._pending = None                       # (front outputs, masked, event) of the batch whose generator has not run yet
+
+    def _streams(self, device):
+        if self.front_stream is None or self.front_stream.device != device:
+            self.front_stream, self.gen_stream = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+
+    @torch.no_grad()
+    def _generate_pending(self):
+        if self._pending is None:
+            return None
+        out, masked, ev = self._pending
+        self._pending = None
+        caller = torch.cuda.current_stream()
+        with torch.cuda.stream(self.gen_stream):
+            self.gen_stream.wait_event(ev)
+            g = self.pipe.generator
+            x = g.pack_input(out['rendered_img'], masked)
+            out['reconstructed_img'] = g.forward_nhwc(x)
+            for t in (out['rendered_img'], masked):
+                t.record_stream(self.gen_stream)
+            done = torch.cuda.Event()
+            done.record(self.gen_stream)
+        caller.wait_event(done)                    # the caller's stream may consume the results
+        for t in out.values():
+            if torch.is_tensor(t):
+                t.record_stream(caller)
+        return out
+
+    @torch.no_grad()
+    def submit(self, img, masked_img, with_landmarks=True):
+        self._streams(img.device)
+        caller = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(caller)                        # inputs were produced on the caller's stream
+        prev = self._generate_pending()             # enqueue generator(i-1) first: it is the long pole
+        p = self.pipe
+        with torch.cuda.stream(self.front_stream):
+            self.front_stream.wait_event(ready)
+            enc = p.encoder(img)
+            fl = p.flame.forward(enc)
+            lm = dict(landmarks_fan=fl['landmarks_fan'], landmarks_mp=fl['landmarks_mp']) if with_landmarks else {}
+            rn = p.renderer.forward(fl['vertices'], enc['cam'], **lm)
+            out = dict(enc)
+            out.update(vertices=fl['vertices'], landmarks_fan_3d=fl['landmarks_fan_3d'], **rn)
+            ev = torch.cuda.Event()
+            ev.record(self.front_stream)
+            img.record_stream(self.front_stream)
+        self._pending = (out, masked_img, ev)
+        return prev
+
+    def flush(self):
+        return self._generate_pending()
+
+
 class OutputGatherer:
     """All-gather of per-rank outputs with equal shard sizes (RCCL on GPUs, gloo in the CPU tests).
 

@@ -8,6 +8,8 @@ The nn.Module tree only HOLDS parameters under timm's state_dict names (`<enc>.e
 stem / depthwise / pool+linear as streaming kernels, every pointwise conv on the fp32 MFMA implicit-GEMM kernel with
 BatchNorm(eval) + ReLU + residual fused.  Eval mode only this round.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -257,6 +259,10 @@ class SmirkEncoder(nn.Module):
         outputs = {}
         if not img.is_cuda:
             raise L.SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
+        if os.environ.get("SMIRK_ENCODER_SERIAL"):              # profiling aid: one stream, reference order
+            for enc in (self.pose_encoder, self.shape_encoder, self.expression_encoder):
+                outputs.update(enc(img))
+            return outputs
         main = torch.cuda.current_stream()
         if img.device not in _STREAMS:
             _STREAMS[img.device] = [torch.cuda.Stream(device=img.device) for _ in range(3)]
