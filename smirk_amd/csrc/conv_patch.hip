@@ -44,14 +44,17 @@ __device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
     }
 }
 
-template <int TN>
-__global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel(PatchArgs a) {
+// NST = number of input stages: 2 = next halo patch DMA'd under the current MFMAs (one workgroup per CU when the weights are large);
+// 1 = single stage, used when weights + one stage fit twice into a CU's 160 KiB: TWO workgroups per CU then cover each other's DMA
+// wait / epilogue, which hides more latency than double buffering a lone 4-wave workgroup.
+template <int TN, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(PatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COUT = TN * 32;
     constexpr int EPI_LD = COUT + 4;
     static_assert(4 * 32 * EPI_LD <= PSTAGE, "transpose buffers must fit in one input stage");
     float* Wl = smem;                                            // [nchunk][9][COUT][32]
-    float* St = smem + a.nchunk * 9 * COUT * 32;                 // 2 input stages
+    float* St = smem + a.nchunk * 9 * COUT * 32;                 // NST input stages
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -123,9 +126,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel(PatchArgs a) {
         item_patch(item, b, oy0, ox0, cc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it                            // stage st (and, first time, the weights) landed; stage st^1 is free
+        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
+        // stage st (and, first time, the weights) has landed
         const int nxt = next_item(item);
-        if (nxt < nitem) issue_item(nxt, st ^ 1);
+        if (NST == 2 && nxt < nitem) issue_item(nxt, st ^ 1);    // the other stage is free: refill it under the MFMAs
         if (cc == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -212,8 +216,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_kernel(PatchArgs a) {
                 __syncthreads();
             }
         }
+        if (NST == 1) {
+            __syncthreads();                                     // everyone is done with the only stage (compute or epilogue)
+            if (nxt < nitem) issue_item(nxt, 0);
+        } else {
+            st ^= 1;
+        }
         item = nxt;
-        st ^= 1;
     }
 }
 
@@ -235,16 +244,21 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
     a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
     a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
     a.npatch = d->B * (d->H / PT) * (d->W / PT);
-    const size_t lds = ((size_t)a.nchunk * 9 * d->Cout * 32 + 2 * PSTAGE) * 4;
-    const int grid = a.npatch < 256 ? a.npatch : 256;
-    static bool attr_done[2] = {false, false};
-    if (d->Cout == 32) {
-        if (!attr_done[0]) { hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
-        hipLaunchKernelGGL(conv3x3_patch_kernel<1>, dim3(grid), dim3(256), lds, st, a);
-    } else {
-        if (!attr_done[1]) { hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
-        hipLaunchKernelGGL(conv3x3_patch_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+    const size_t wbytes = (size_t)a.nchunk * 9 * d->Cout * 32 * 4;
+    const bool one_stage = (wbytes + (size_t)PSTAGE * 4) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
+    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4;
+    const int cap = one_stage ? 512 : 256;
+    const int grid = a.npatch < cap ? a.npatch : cap;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
     }
+    if (d->Cout == 32 && one_stage) hipLaunchKernelGGL((conv3x3_patch_kernel<1, 1>), dim3(grid), dim3(256), lds, st, a);
+    else if (d->Cout == 32) hipLaunchKernelGGL((conv3x3_patch_kernel<1, 2>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<2, 2>), dim3(grid), dim3(256), lds, st, a);
     return smirk_launch_status();
 }
 
