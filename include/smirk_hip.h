@@ -117,6 +117,10 @@ int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, int W,
                          int64_t* pix_to_face, float* bary, float* zbuf, float* normals,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* util.vertex_normals (util.py:30-62) on a FULL mesh (mesh->Vf == mesh->V, mesh->faces index the vertices directly, mesh->keep unused):
+ * verts[B][V][3] -> normals[B][V][3], CSR accumulation order as in smirk_render_forward.  Used by utils/masking.py:146. */
+int smirk_vertex_normals(const SmirkRenderMesh* mesh, int B, const float* verts, float* normals, void* stream);
+
 /* Landmark projection (renderer.py:104-108): lmk[B][L][3], cam[B][3] -> out[B][L][2]. */
 int smirk_project_landmarks(const float* lmk, const float* cam, int B, int L, float* out, void* stream);
 
@@ -190,6 +194,33 @@ int smirk_gap_linear(const float* feat, const float* w, const float* bias, float
 /* ExpressionEncoder output clamps (smirk_encoder.py:104-108), in place on params[B][n_exp+5]:
  * [n_exp, n_exp+2) clamp(0,1); [n_exp+2] relu; [n_exp+3, n_exp+5) clamp(-.2,.2). */
 int smirk_expression_clamps(float* params, int B, int n_exp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Masking utilities between Renderer and SmirkGenerator (src/utils/masking.py).
+ * Random draws come from a counter-based Philox4x32-10 stream keyed by (seed, offset): reproducible, but not torch's streams.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* sampling weight per (image, triangle): (mean vertex-normal z < 0.05 ? face_prob : 0) * xy shoelace area   (masking.py:144-160).
+ * tverts = Renderer's transformed_vertices [B][V][3]; normals = smirk_vertex_normals of them. */
+int smirk_mask_face_weights(const float* tverts, const float* normals, const int32_t* faces /*[F][3]*/, const float* face_prob /*[F]*/,
+                            int B, int V, int F, float* weights /*[B][F]*/, void* stream);
+/* multinomial(weights, num, replacement=True) + random_barycentric (masking.py:51-68,163-166): idx[B][num] int32, bary[B][num][3]. */
+int smirk_sample_faces(const float* weights, int B, int F, int num, uint64_t seed, uint64_t offset, int32_t* idx, float* bary,
+                       void* stream);
+/* npoints = (.5 * (1 + p) * S).long(), x and y clamped to [0, S-1] (masking.py:172-175): points[B][L][3] -> out[B][L][3] int64. */
+int smirk_points_to_pixels(const float* points, int B, int L, int image_size, int64_t* out, void* stream);
+/* out = max_pool2d(in, 2r+1, stride 1, padding r) on [B][1][H][W] as two separable passes (tmp = scratch of the same size).
+ * complement bit 0: pool (1 - in) instead of in; bit 1: return 1 - result.  3 => 1 - maxpool(1 - in) (masking.py:78), 2 => 1 - maxpool(in) (:96). */
+int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int W, int radius, int complement, void* stream);
+int smirk_bernoulli_field(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* masking.py:84-101: out = extra' > 0 ? extra' : img * mask * (1 - rendered_mask), extra' = extra_points * noise * keep.
+ * noise_mult (nullable, [B][C][H][W]) overrides the generated N(1, 0.05) field; gen_noise = 0 and noise_mult = NULL => no noise. */
+int smirk_masking_compose(const float* img, const float* mask, const float* rendered_mask, const float* extra_points,
+                          const float* keep, const float* noise_mult, int B, int C, int H, int W, int gen_noise,
+                          uint64_t seed, uint64_t offset, float* out, void* stream);
+/* transfer_pixels (masking.py:116-129): out[b,:,p2y,p2x] = img[b,:,p1y,p1x] for l < rbound[b] (rbound nullable), 0 elsewhere;
+ * duplicate targets: the highest l wins.  points [B][L][3] int64 (x, y, .), winner_ws [B][H][W] int32 scratch. */
+int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_t* points2, const int64_t* rbound, int B, int C,
+                          int L, int H, int W, int32_t* winner_ws, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,9 @@ def build_bundle_from_reference(ref_root, out_npz=BUNDLE):
     )
     for k, val in masks.items():
         out["mask_" + k] = np.asarray(val)
+    tri = np.load(os.path.join(a, "FLAME_masks", "FLAME_masks_triangles.npy"), allow_pickle=True).item()
+    for k, val in tri.items():
+        out["tri_" + k] = np.asarray(val).astype(np.int32)
     os.makedirs(os.path.dirname(out_npz), exist_ok=True)
     np.savez_compressed(out_npz, **out)
     return out_npz

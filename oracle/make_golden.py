@@ -72,6 +72,39 @@ def main():
         np.savez_compressed(os.path.join(GOLD, "encoder_golden.npz"), seed=31,
                             w_checksum=np.float64(sum(float(v.double().abs().sum()) for v in esd.values())),
                             **{k: v.numpy() for k, v in eo.items()})
+        # ---- masking utilities (deterministic parts) -------------------------------
+        Mk = ref.masking
+        tv = ro["transformed_vertices"]
+        faces_t = fl.faces_tensor
+        prob = Mk.load_probabilities_per_FLAME_triangle()
+        B2 = tv.shape[0]
+        fexp = faces_t.expand(B2, -1, -1)
+        nrm = ref.render_util.vertex_normals(tv, fexp)
+        fnz = ref.render_util.face_vertices(nrm, fexp)[:, :, :, 2].mean(dim=-1)
+        w = torch.where(fnz < 0.05, prob.repeat(B2, 1), torch.zeros_like(fnz)) * Mk.triangle_area(ref.render_util.face_vertices(tv, fexp))
+        g = torch.Generator().manual_seed(5)
+        n_pts = int(0.01 * 224 * 224)
+        idx = torch.multinomial(w, n_pts, replacement=True, generator=g)
+        u, v = torch.rand(B2 * n_pts, generator=g), torch.rand(B2 * n_pts, generator=g)
+        o = (u + v) > 1
+        u[o], v[o] = 1 - u[o], 1 - v[o]
+        bary = torch.stack((1 - (u + v), u, v), 1).view(B2, n_pts, 3)
+        npts, _ = Mk.mesh_based_mask_uniform_faces(tv, faces_t, prob, mask_ratio=0.01,
+                                                   coords={"sampled_faces_indices": idx, "barycentric_coords": bary})
+        img_m = A.synth_images(B2, seed=41)
+        hull = (A.synth_generator_input(B2, seed=41)[:, 3:4] == 0).float()          # a disc, stand-in for the landmark hull mask
+        rmask = 1 - (ro["rendered_img"] == 0).all(dim=1, keepdim=True).float()
+        pmask = torch.zeros_like(rmask)
+        for bi in range(B2):
+            pmask[bi, :, npts[bi, :, 1], npts[bi, :, 0]] = 1
+        extra = img_m * pmask
+        masked = Mk.masking(img_m, hull, extra, 10, rendered_mask=rmask, extra_noise=False, random_mask=0)
+        npts2 = torch.flip(npts, [1])
+        tp = Mk.transfer_pixels(img_m, npts, npts2)
+        np.savez_compressed(os.path.join(GOLD, "masking_golden.npz"), weights=w.numpy(), idx=idx.numpy().astype(np.int32),
+                            bary=bary.numpy(), npoints=npts.numpy(), masked_sub2=masked.numpy()[:, :, ::2, ::2],
+                            masked_sum=np.float64(masked.double().sum()), transfer_nonzero=np.int64((tp != 0).sum()),
+                            transfer_sum=np.float64(tp.double().sum()), img_seed=41)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
 

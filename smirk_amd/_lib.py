@@ -48,6 +48,14 @@ _SIGS = {
     "smirk_vertices2landmarks": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p]),
     "smirk_render_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
     "smirk_render_forward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "smirk_vertex_normals": (_i, [C.POINTER(SmirkRenderMesh), _i, _p, _p, _p]),
+    "smirk_mask_face_weights": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "smirk_sample_faces": (_i, [_p, _i, _i, _i, C.c_uint64, C.c_uint64, _p, _p, _p]),
+    "smirk_points_to_pixels": (_i, [_p, _i, _i, _i, _p, _p]),
+    "smirk_maxpool_sq": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smirk_bernoulli_field": (_i, [_p, _sz, C.c_float, C.c_uint64, C.c_uint64, _p]),
+    "smirk_masking_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint64, _p, _p]),
+    "smirk_transfer_pixels": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_project_landmarks": (_i, [_p, _p, _i, _i, _p, _p]),
     "smirk_conv_igemm_f32": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_conv_igemm_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),

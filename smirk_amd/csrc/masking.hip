@@ -1,0 +1,239 @@
+// Mesh-based masking utilities for MI355X (gfx950) — the step between Renderer and SmirkGenerator
+// (src/utils/masking.py:39-181; callers demo.py:146-167, smirk_trainer.py:76-93,268-293).  All HBM/latency-bound integer + fp32 work:
+//   mask_face_weights   per (image, FLAME triangle): mean z of its 3 vertex normals, visibility gate (< 0.05), xy shoelace area,
+//                       region probability  -> sampling weight                                  (masking.py:144-160)
+//   sample_faces        one workgroup per image: LDS prefix sum of the 9976 weights (the CDF), then every lane draws with a counter-
+//                       based Philox4x32-10 generator and binary-searches the CDF (multinomial with replacement) and draws the
+//                       folded-uniform barycentrics                                            (masking.py:51-68,163-166)
+//   points_to_pixels    .5*(1+p)*S -> int64 (truncation) -> clamp x,y                          (masking.py:172-175)
+//   maxpool_sq          (2r+1)^2 stride-1 max pool with -inf padding as two separable passes   (masking.py:78,96)
+//   bernoulli_field / masking_compose / transfer_pixels                                        (masking.py:71-102,116-129)
+// Random draws are reproducible from (seed, call offset) but are NOT torch's CPU/CUDA streams — the reference itself draws
+// different numbers on CPU and GPU; deterministic entry points (coords= / explicit fields) are what the parity tests pin.
+#include "common.h"
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = (idx, stream, 0, 0), key = seed ------------------------------------------------
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1), 24 bits like torch.rand
+
+__global__ __launch_bounds__(256) void mask_face_weights_kernel(const float* __restrict__ tv, const float* __restrict__ normals,
+                                                                const int32_t* __restrict__ faces, const float* __restrict__ prob,
+                                                                int B, int V, int F, float* __restrict__ w) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * F) return;
+    const int b = (int)(i / F), f = (int)(i % F);
+    const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+    const float* nb = normals + (size_t)b * V * 3;
+    const float* vb = tv + (size_t)b * V * 3;
+    const float nz = ((nb[i0 * 3 + 2] + nb[i1 * 3 + 2]) + nb[i2 * 3 + 2]) / 3.0f;
+    const float x1 = vb[i0 * 3], y1 = vb[i0 * 3 + 1], x2 = vb[i1 * 3], y2 = vb[i1 * 3 + 1], x3 = vb[i2 * 3], y3 = vb[i2 * 3 + 1];
+    const float area = 0.5f * fabsf(x1 * y2 + x2 * y3 + x3 * y1 - x2 * y1 - x3 * y2 - x1 * y3);
+    const float p = (nz < 0.05f) ? prob[f] : 0.0f;
+    w[i] = p * area;
+}
+
+__global__ __launch_bounds__(1024) void sample_faces_kernel(const float* __restrict__ w, int F, int num, uint64_t seed,
+                                                            uint64_t offset, int32_t* __restrict__ idx, float* __restrict__ bary) {
+    extern __shared__ float cdf[];               // [F] inclusive prefix sums, + 32 wave totals
+    float* wtot = cdf + F;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float* wb = w + (size_t)b * F;
+    // block scan in chunks of blockDim: sequential carry keeps the summation order fixed (deterministic)
+    float carry = 0.f;
+    for (int base = 0; base < F; base += blockDim.x) {
+        const int i = base + tid;
+        float v = (i < F) ? wb[i] : 0.f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+        if (lane == 63) wtot[wave] = v;
+        __syncthreads();
+        float pre = carry;
+        for (int k = 0; k < wave; ++k) pre += wtot[k];
+        if (i < F) cdf[i] = v + pre;
+        float all = carry;
+        for (int k = 0; k < nw; ++k) all += wtot[k];
+        __syncthreads();
+        carry = all;
+    }
+    const float total = carry;
+    for (int t = tid; t < num; t += blockDim.x) {
+        uint32_t r[4];
+        const uint64_t ctr = offset + (uint64_t)b * num + t;
+        philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        const float target = u01(r[0]) * total;
+        int lo = 0, hi = F - 1;                  // first index whose cdf exceeds target (zero-weight faces are never chosen)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > target) hi = mid; else lo = mid + 1; }
+        idx[(size_t)b * num + t] = lo;
+        float u = u01(r[1]), v = u01(r[2]);
+        if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }                       // masking.py:58-60
+        float* o = bary + ((size_t)b * num + t) * 3;
+        o[0] = 1.0f - (u + v); o[1] = u; o[2] = v;                             // masking.py:63-68
+    }
+}
+
+__global__ __launch_bounds__(256) void points_to_pixels_kernel(const float* __restrict__ p, size_t n, int S, long long* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = 0.5f * (1.0f + p[i * 3 + c]) * (float)S;               // masking.py:172
+        long long q = (long long)v;                                             // .long(): truncation toward zero
+        if (c < 2) q = q < 0 ? 0 : (q > S - 1 ? S - 1 : q);                     // masking.py:174-175
+        out[i * 3 + c] = q;
+    }
+}
+
+// one pass of a separable (2r+1) max filter with -inf padding; dir 0 = along x, 1 = along y.  in/out [B][H][W]
+__global__ __launch_bounds__(256) void maxfilter1d_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                          int r, int dir, int complement_in, int complement_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const size_t base = i - (size_t)y * W - x;
+    float m = -INFINITY;
+    if (dir == 0) {
+        const int lo = max(x - r, 0), hi = min(x + r, W - 1);
+        for (int k = lo; k <= hi; ++k) { float v = in[base + (size_t)y * W + k]; if (complement_in) v = 1.0f - v; m = fmaxf(m, v); }
+    } else {
+        const int lo = max(y - r, 0), hi = min(y + r, H - 1);
+        for (int k = lo; k <= hi; ++k) { float v = in[base + (size_t)k * W + x]; if (complement_in) v = 1.0f - v; m = fmaxf(m, v); }
+    }
+    out[i] = complement_out ? 1.0f - m : m;
+}
+
+__global__ __launch_bounds__(256) void bernoulli_field_kernel(float* __restrict__ out, size_t n, float p, uint64_t seed, uint64_t offset) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    uint32_t r[4];
+    const uint64_t ctr = offset + i4 / 4;
+    philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i4 + k < n) out[i4 + k] = u01(r[k]) < p ? 1.0f : 0.0f;
+}
+
+// masked = img * mask * (1 - rendered_mask); extra = extra_points * (noise ? N(1, 0.05) : 1) * keep; out = extra > 0 ? extra : masked
+// img / extra / out [B][C][H][W]; mask, rendered_mask, keep [B][1][H][W] (rendered_mask / keep nullable)
+__global__ __launch_bounds__(256) void masking_compose_kernel(const float* __restrict__ img, const float* __restrict__ mask,
+                                                              const float* __restrict__ rendered_mask,
+                                                              const float* __restrict__ extra, const float* __restrict__ keep,
+                                                              const float* __restrict__ noise_mult, int B, int C, int HW,
+                                                              int gen_noise, uint64_t seed, uint64_t offset,
+                                                              float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * C * HW) return;
+    const size_t b = i / ((size_t)C * HW), p = i % HW;
+    float m = mask[b * HW + p];
+    if (rendered_mask) m = m * (1.0f - rendered_mask[b * HW + p]);
+    const float masked = img[i] * m;
+    float e = extra[i];
+    if (noise_mult) e = e * noise_mult[i];
+    else if (gen_noise) {
+        uint32_t r[4];
+        const uint64_t ctr = offset + i;
+        philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 2u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        const float u1 = fmaxf(u01(r[0]), 5.96e-8f), u2 = u01(r[1]);
+        const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);      // Box-Muller
+        e = e * (z * 0.05f + 1.0f);                                                          // masking.py:91-92
+    }
+    if (keep) e = e * keep[b * HW + p];
+    out[i] = (e > 0.0f) ? e : masked;                                                        // masking.py:101
+}
+
+// retained[b,:,p2y,p2x] = img[b,:,p1y,p1x] for l < rbound[b]; duplicates in points2: the highest l wins (CPU index_put order)
+__global__ __launch_bounds__(256) void transfer_winner_kernel(const long long* __restrict__ p2, const long long* __restrict__ rbound,
+                                                              int B, int L, int H, int W, int* __restrict__ winner) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L) return;
+    const int b = (int)(i / L), l = (int)(i % L);
+    if (rbound && l >= rbound[b]) return;
+    const long long x = p2[i * 3 + 0], y = p2[i * 3 + 1];
+    if (x < 0 || x >= W || y < 0 || y >= H) return;
+    atomicMax(&winner[((size_t)b * H + y) * W + x], l);
+}
+__global__ __launch_bounds__(256) void transfer_gather_kernel(const float* __restrict__ img, const long long* __restrict__ p1,
+                                                              const int* __restrict__ winner, int B, int C, int L, int H, int W,
+                                                              float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * C * H * W) return;
+    const size_t HW = (size_t)H * W, b = i / (C * HW), c = (i / HW) % C, p = i % HW;
+    const int l = winner[b * HW + p];
+    float v = 0.f;
+    if (l >= 0) {
+        long long x = p1[((size_t)b * L + l) * 3 + 0], y = p1[((size_t)b * L + l) * 3 + 1];
+        x = x < 0 ? x + W : x; y = y < 0 ? y + H : y;                    // python negative indexing never occurs after the clamps; kept for safety
+        v = img[(b * C + c) * HW + (size_t)y * W + x];
+    }
+    out[i] = v;
+}
+
+static unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" int smirk_mask_face_weights(const float* tverts, const float* normals, const int32_t* faces, const float* face_prob,
+                                       int B, int V, int F, float* weights, void* stream) {
+    if (!tverts || !normals || !faces || !face_prob || !weights || B <= 0 || F <= 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mask_face_weights_kernel, dim3(nblk((size_t)B * F)), dim3(256), 0, (hipStream_t)stream, tverts, normals, faces,
+                       face_prob, B, V, F, weights);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_sample_faces(const float* weights, int B, int F, int num, uint64_t seed, uint64_t offset, int32_t* idx,
+                                  float* bary, void* stream) {
+    if (!weights || !idx || !bary || B <= 0 || F <= 0 || num <= 0 || F > 38000) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sample_faces_kernel, dim3(B), dim3(1024), (size_t)(F + 32) * 4, (hipStream_t)stream, weights, F, num, seed,
+                       offset, idx, bary);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_points_to_pixels(const float* points, int B, int L, int image_size, int64_t* out, void* stream) {
+    if (!points || !out || B <= 0 || L <= 0 || image_size <= 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(points_to_pixels_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, (hipStream_t)stream, points, (size_t)B * L,
+                       image_size, (long long*)out);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int W, int radius, int complement, void* stream) {
+    if (!in || !tmp || !out || B <= 0 || radius < 0) return SMIRK_ERR_BAD_ARG;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in, tmp, B, H, W, radius, 0, complement & 1, 0);
+    hipLaunchKernelGGL(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, out, B, H, W, radius, 1, 0,
+                       (complement >> 1) & 1);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_bernoulli_field(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n == 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bernoulli_field_kernel, dim3(nblk((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, p, seed, offset);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_masking_compose(const float* img, const float* mask, const float* rendered_mask, const float* extra_points,
+                                     const float* keep, const float* noise_mult, int B, int C, int H, int W, int gen_noise,
+                                     uint64_t seed, uint64_t offset, float* out, void* stream) {
+    if (!img || !mask || !extra_points || !out || B <= 0 || C <= 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(masking_compose_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, img, mask,
+                       rendered_mask, extra_points, keep, noise_mult, B, C, H * W, gen_noise, seed, offset, out);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_t* points2, const int64_t* rbound, int B,
+                                     int C, int L, int H, int W, int32_t* winner_ws, float* out, void* stream) {
+    if (!img || !points1 || !points2 || !winner_ws || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(winner_ws, 0xFF, (size_t)B * H * W * 4, st) != hipSuccess) return SMIRK_ERR_LAUNCH;   // -1
+    hipLaunchKernelGGL(transfer_winner_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, st, (const long long*)points2,
+                       (const long long*)rbound, B, L, H, W, winner_ws);
+    hipLaunchKernelGGL(transfer_gather_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, st, img, (const long long*)points1,
+                       (const int*)winner_ws, B, C, L, H, W, out);
+    return smirk_launch_status();
+}

@@ -263,6 +263,41 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
     return smirk_launch_status();
 }
 
+// vertex normals on their own (used by utils/masking.py:146 on the FULL mesh of the transformed vertices): mesh->keep may be NULL => identity
+__global__ __launch_bounds__(256) void normals_full_kernel(MeshDev m, int B, const float* __restrict__ verts, float* __restrict__ normals) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * m.Vf) return;
+    const int b = (int)(i / m.Vf), vi = (int)(i % m.Vf);
+    const float* vb = verts + (size_t)b * m.V * 3;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int e = m.nrm_ptr[vi]; e < m.nrm_ptr[vi + 1]; ++e) {
+        const int f = m.nrm_face[e], c = m.nrm_corner[e];
+        float p[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int g = m.faces[f * 3 + k];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) p[k][d] = vb[g * 3 + d];
+        }
+        const int i0 = c, i1 = (c + 1) % 3, i2 = (c + 2) % 3;
+        float a[3], bb[3], cr[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { a[d] = p[i1][d] - p[i0][d]; bb[d] = p[i2][d] - p[i0][d]; }
+        cross3(a, bb, cr);
+        n[0] += cr[0]; n[1] += cr[1]; n[2] += cr[2];
+    }
+    const float den = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-6f);
+    normals[i * 3 + 0] = n[0] / den; normals[i * 3 + 1] = n[1] / den; normals[i * 3 + 2] = n[2] / den;
+}
+
+extern "C" int smirk_vertex_normals(const SmirkRenderMesh* mesh, int B, const float* verts, float* normals, void* stream) {
+    if (!mesh || !verts || !normals || B <= 0 || mesh->Vf != mesh->V) return SMIRK_ERR_BAD_ARG;   // full mesh only (faces index verts directly)
+    const MeshDev d = mesh_dev(mesh);
+    const size_t n = (size_t)B * mesh->Vf;
+    hipLaunchKernelGGL(normals_full_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, B, verts, normals);
+    return smirk_launch_status();
+}
+
 extern "C" int smirk_project_landmarks(const float* lmk, const float* cam, int B, int L, float* out, void* stream) {
     if (!lmk || !cam || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)B * L;

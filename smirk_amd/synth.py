@@ -82,6 +82,9 @@ def write_sandbox(root, bundle=None, seed=2020):
     masks = {k[5:]: bundle[k] for k in bundle if k.startswith("mask_")}
     with open(os.path.join(a, "FLAME_masks", "FLAME_masks.pkl"), "wb") as fh:
         pickle.dump(masks, fh, protocol=2)
+    tris = {k[4:]: bundle[k].astype(np.int64) for k in bundle if k.startswith("tri_")}
+    if tris:
+        np.save(os.path.join(a, "FLAME_masks", "FLAME_masks_triangles.npy"), np.array(tris, dtype=object), allow_pickle=True)
     np.savez(os.path.join(a, "mediapipe_landmark_embedding", "mediapipe_landmark_embedding.npz"),
              lmk_face_idx=bundle["mp_lmk_face_idx"], lmk_b_coords=bundle["mp_lmk_b_coords"],
              landmark_indices=bundle["mp_landmark_indices"])

@@ -197,3 +197,34 @@ def test_c_abi_exports_every_declared_symbol():
         getattr(dll, name)
     dll.smirk_strerror.restype = ctypes.c_char_p
     assert dll.smirk_strerror(0) == b"ok" and dll.smirk_abi_version() == _lib.ABI_VERSION
+
+
+def test_masking_oracle_vs_reference_golden(sandbox, golden_dir):
+    """oracle/masking_ref.py against outputs of the reference's src/utils/masking.py functions (deterministic parts)."""
+    from oracle import masking_ref as MR
+    g = np.load(os.path.join(golden_dir, "masking_golden.npz"))
+    r = np.load(os.path.join(golden_dir, "render_golden.npz"))
+    fr = FlameRef(sandbox)
+    tv = r["transformed_vertices"]
+    b = A.load_bundle()
+    prob = np.zeros(9976, np.float32)
+    wts = {'neck': 0.0, 'right_eyeball': 0.0, 'right_ear': 0.0, 'lips': 0.5, 'nose': 0.5, 'left_ear': 0.0, 'eye_region': 1.0, 'forehead': 1.0,
+           'left_eye_region': 1.0, 'right_eye_region': 1.0, 'face_clean': 1.0, 'cleaner_lips': 1.0}
+    for k, v in wts.items():
+        prob[b["tri_" + k]] = v
+    w = MR.face_weights(tv, fr.faces, prob)
+    assert np.array_equal(w > 0, g["weights"] > 0)
+    assert np.abs(w - g["weights"]).max() < 1e-7
+    pts, _ = MR.points_from_coords(tv, fr.faces, g["idx"].astype(np.int64), g["bary"])
+    assert (pts != g["npoints"]).mean() < 1e-3 and np.abs(pts - g["npoints"]).max() <= 1
+    img = A.synth_images(2, seed=int(g["img_seed"])).numpy()
+    hull = (A.synth_generator_input(2, seed=int(g["img_seed"]))[:, 3:4] == 0).float().numpy()
+    rimg = R.RendererRef(sandbox).forward(np.load(os.path.join(golden_dir, "flame_golden.npz"))["vertices"][:2], r["cam"])["rendered_img"]
+    rmask = 1 - (rimg == 0).all(1, keepdims=True).astype(np.float32)
+    pmask = np.zeros_like(rmask)
+    for bi in range(2):
+        pmask[bi, :, g["npoints"][bi, :, 1], g["npoints"][bi, :, 0]] = 1
+    masked = MR.masking(img, hull, img * pmask, 10, rendered_mask=rmask)
+    assert np.abs(masked[:, :, ::2, ::2] - g["masked_sub2"]).max() < 1e-6
+    tp = MR.transfer_pixels(img, g["npoints"], g["npoints"][:, ::-1])
+    assert int((tp != 0).sum()) == int(g["transfer_nonzero"]) and abs(tp.astype(np.float64).sum() - float(g["transfer_sum"])) < 1e-3
