@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run each batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
+    ap.add_argument("--given-masked", action="store_true",
+                    help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
     ap.add_argument("--cpu-faces", type=int, default=96, help="sample size of the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -119,10 +121,20 @@ def main():
     from smirk_amd.pipeline import OutputGatherer, OverlappedPipeline, SmirkPipeline
     sandbox = tempfile.mkdtemp(prefix=f"smirk_bench_r{rank}_")
     enc, flame, rend, gen = build_modules(sandbox, dev)
-    pipe = SmirkPipeline(enc, flame, rend, gen)
+    from smirk_amd import masking as MK
+    cwd = os.getcwd(); os.chdir(sandbox)
+    try:
+        face_prob = MK.load_probabilities_per_FLAME_triangle().to(dev)
+    finally:
+        os.chdir(cwd)
+    pipe = SmirkPipeline(enc, flame, rend, gen, face_probabilities=face_prob)
     B = args.batch
     img = synth.synth_images(B, seed=1000 + rank).to(dev)                  # resident in HBM before the timed region
     masked = synth.synth_generator_input(B, seed=1000 + rank)[:, 3:].contiguous().to(dev)
+    # hull mask (1 = keep the photo, 0 = face region): a synthetic disc stands in for demo.py's mediapipe/cv2 convex hull (CPU preprocessing,
+    # out of scope); the masked image itself is then produced on the GPU by the masking utilities exactly as demo.py:138-165 does
+    hull = (synth.synth_generator_input(B, seed=1000 + rank)[:, 3:4] != 0).float().contiguous().to(dev)
+    kw = dict(masked_img=masked) if args.given_masked else dict(hull_mask=hull)
     gather = OutputGatherer()
     runner = OverlappedPipeline(pipe) if args.overlap else None
 
@@ -134,9 +146,9 @@ def main():
         """one batch of B frames enters the path; with --overlap its generator stage runs under the next batch's front stages
         (independent batches, identical results) and completes in the next step() / in drain()."""
         if runner is None:
-            finish(pipe(img, masked, with_landmarks=True))
+            finish(pipe(img, with_landmarks=True, **kw))
         else:
-            done = runner.submit(img, masked)
+            done = runner.submit(img, **kw)
             if done is not None:
                 finish(done)
 
@@ -173,7 +185,7 @@ def main():
     roof = None
     if rank == 0:
         L.TIMER = []
-        finish(pipe(img, masked, with_landmarks=True)); gather.wait(); torch.cuda.synchronize()
+        finish(pipe(img, with_landmarks=True, **kw)); gather.wait(); torch.cuda.synchronize()
         per = {}
         for name, flops, e0, e1 in L.TIMER:
             a = per.setdefault(name, [0.0, 0.0, 0])
@@ -220,6 +232,7 @@ def main():
                        "frames_per_gpu": B, "global_batch": B * world, "image": "224x224", "parallelism": f"dp{world}",
                        "collective": "async all_gather(vertices, rendered_img, reconstructed_img)" if world > 1 else "none (1 GPU)",
                        "weights": "random-init reference architecture (no checkpoint offline)",
+                       "masking": "given masked image" if args.given_masked else "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",
                        "schedule": "2-stream software pipeline: generator(batch i) || encode+FLAME+render(batch i+1)" if args.overlap else "serial stages"},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "path_tflops_per_gpu": value / world * FLOP_PER_FACE / 1e12,

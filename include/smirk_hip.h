@@ -214,9 +214,14 @@ int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int 
 int smirk_bernoulli_field(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 /* masking.py:84-101: out = extra' > 0 ? extra' : img * mask * (1 - rendered_mask), extra' = extra_points * noise * keep.
  * noise_mult (nullable, [B][C][H][W]) overrides the generated N(1, 0.05) field; gen_noise = 0 and noise_mult = NULL => no noise. */
-int smirk_masking_compose(const float* img, const float* mask, const float* rendered_mask, const float* extra_points,
+int smirk_masking_compose(const float* img, const float* mask, const float* rendered_mask, const float* extra_points /*nullable*/,
+                          const float* pmask /*nullable [B][1][H][W]: extra_points = img * pmask (demo.py:163) when extra_points is NULL*/,
                           const float* keep, const float* noise_mult, int B, int C, int H, int W, int gen_noise,
                           uint64_t seed, uint64_t offset, float* out, void* stream);
+/* caller glue of demo.py:146,153-159 / smirk_trainer.py:79,86-88: rendered_mask = 1 - (rendered_img == 0).all(dim=1) -> [B][1][H][W];
+ * pmask = 1 at the first rbound[b] (nullable: all) sampled pixel positions points[B][L][3] int64 (x, y, .) -> [B][1][H][W]. */
+int smirk_rendered_mask(const float* rendered_img, int B, int C, int H, int W, float* out, void* stream);
+int smirk_scatter_points_mask(const int64_t* points, const int64_t* rbound, int B, int L, int H, int W, float* out, void* stream);
 /* transfer_pixels (masking.py:116-129): out[b,:,p2y,p2x] = img[b,:,p1y,p1x] for l < rbound[b] (rbound nullable), 0 elsewhere;
  * duplicate targets: the highest l wins.  points [B][L][3] int64 (x, y, .), winner_ws [B][H][W] int32 scratch. */
 int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_t* points2, const int64_t* rbound, int B, int C,

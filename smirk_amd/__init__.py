@@ -10,5 +10,6 @@ from .FLAME import FLAME  # noqa: F401
 from .renderer import Renderer  # noqa: F401
 from .smirk_encoder import SmirkEncoder  # noqa: F401
 from .smirk_generator import SmirkGenerator  # noqa: F401
+from . import masking  # noqa: F401  (drop-in for src/utils/masking.py)
 
-__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib"]
+__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib", "masking"]

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void bernoulli_field_kernel(float* __restrict_
 // img / extra / out [B][C][H][W]; mask, rendered_mask, keep [B][1][H][W] (rendered_mask / keep nullable)
 __global__ __launch_bounds__(256) void masking_compose_kernel(const float* __restrict__ img, const float* __restrict__ mask,
                                                               const float* __restrict__ rendered_mask,
-                                                              const float* __restrict__ extra, const float* __restrict__ keep,
+                                                              const float* __restrict__ extra, const float* __restrict__ pmask,
+                                                              const float* __restrict__ keep,
                                                               const float* __restrict__ noise_mult, int B, int C, int HW,
                                                               int gen_noise, uint64_t seed, uint64_t offset,
                                                               float* __restrict__ out) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void masking_compose_kernel(const float* __res
     float m = mask[b * HW + p];
     if (rendered_mask) m = m * (1.0f - rendered_mask[b * HW + p]);
     const float masked = img[i] * m;
-    float e = extra[i];
+    float e = extra ? extra[i] : img[i] * pmask[b * HW + p];                                 // demo.py:163 extra_points = image * pmask
     if (noise_mult) e = e * noise_mult[i];
     else if (gen_noise) {
         uint32_t r[4];
@@ -177,7 +178,42 @@ __global__ __launch_bounds__(256) void transfer_gather_kernel(const float* __res
     out[i] = v;
 }
 
+// pmask[b,0,y,x] = 1 at the first rbound[b] sampled points (demo.py:153-159, smirk_trainer.py:86-88); out must be zero-filled
+__global__ __launch_bounds__(256) void scatter_points_kernel(const long long* __restrict__ pts, const long long* __restrict__ rbound,
+                                                             int B, int L, int H, int W, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L) return;
+    const int b = (int)(i / L), l = (int)(i % L);
+    if (rbound && l >= rbound[b]) return;
+    const long long x = pts[i * 3], y = pts[i * 3 + 1];
+    if (x >= 0 && x < W && y >= 0 && y < H) out[((size_t)b * H + y) * W + x] = 1.0f;
+}
+// rendered_mask = 1 - (rendered_img == 0).all(dim=1)   (demo.py:146, smirk_trainer.py:79)
+__global__ __launch_bounds__(256) void rendered_mask_kernel(const float* __restrict__ img, int B, int C, int HW, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW) return;
+    const size_t b = i / HW, p = i % HW;
+    bool all0 = true;
+    for (int c = 0; c < C; ++c) all0 = all0 && (img[(b * C + c) * HW + p] == 0.0f);
+    out[i] = all0 ? 0.0f : 1.0f;
+}
+
 static unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" int smirk_scatter_points_mask(const int64_t* points, const int64_t* rbound, int B, int L, int H, int W, float* out, void* stream) {
+    if (!points || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, (size_t)B * H * W * 4, st) != hipSuccess) return SMIRK_ERR_LAUNCH;
+    hipLaunchKernelGGL(scatter_points_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, st, (const long long*)points, (const long long*)rbound,
+                       B, L, H, W, out);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_rendered_mask(const float* rendered_img, int B, int C, int H, int W, float* out, void* stream) {
+    if (!rendered_img || !out || B <= 0 || C <= 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(rendered_mask_kernel, dim3(nblk((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, rendered_img, B, C, H * W, out);
+    return smirk_launch_status();
+}
 
 extern "C" int smirk_mask_face_weights(const float* tverts, const float* normals, const int32_t* faces, const float* face_prob,
                                        int B, int V, int F, float* weights, void* stream) {
@@ -218,11 +254,11 @@ extern "C" int smirk_bernoulli_field(float* out, size_t n, float p, uint64_t see
 }
 
 extern "C" int smirk_masking_compose(const float* img, const float* mask, const float* rendered_mask, const float* extra_points,
-                                     const float* keep, const float* noise_mult, int B, int C, int H, int W, int gen_noise,
-                                     uint64_t seed, uint64_t offset, float* out, void* stream) {
-    if (!img || !mask || !extra_points || !out || B <= 0 || C <= 0) return SMIRK_ERR_BAD_ARG;
+                                     const float* pmask, const float* keep, const float* noise_mult, int B, int C, int H, int W,
+                                     int gen_noise, uint64_t seed, uint64_t offset, float* out, void* stream) {
+    if (!img || !mask || (!extra_points && !pmask) || !out || B <= 0 || C <= 0) return SMIRK_ERR_BAD_ARG;
     hipLaunchKernelGGL(masking_compose_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, img, mask,
-                       rendered_mask, extra_points, keep, noise_mult, B, C, H * W, gen_noise, seed, offset, out);
+                       rendered_mask, extra_points, pmask, keep, noise_mult, B, C, H * W, gen_noise, seed, offset, out);
     return smirk_launch_status();
 }
 

@@ -16,16 +16,11 @@ import torch
 from . import _lib as L
 from .renderer import normal_csr
 
-_rng_state = {"seed": None, "offset": 0}
-
-
 def _rng(n_draws):
-    """(seed, offset) for the next n_draws counters; the stream restarts whenever torch's global seed changes."""
+    """(seed, offset) of the Philox counters for one call: the key is torch's global seed and the counter base is drawn from torch's
+    default (CPU) generator, so `torch.manual_seed(s)` makes a whole sequence of calls reproducible while successive calls differ."""
     seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-    if _rng_state["seed"] != seed:
-        _rng_state["seed"], _rng_state["offset"] = seed, 0
-    off = _rng_state["offset"]
-    _rng_state["offset"] = off + int(n_draws)
+    off = int(torch.randint(0, 2 ** 62, (1,)).item())
     return seed, off
 
 
@@ -63,10 +58,13 @@ def _maxpool_sq(x, radius, complement):
     return out
 
 
-def masking(img, mask, extra_points, wr=15, rendered_mask=None, extra_noise=True, random_mask=0.01, _noise_mult=None, _random_field=None):
+def masking(img, mask, extra_points, wr=15, rendered_mask=None, extra_noise=True, random_mask=0.01, _noise_mult=None, _random_field=None,
+            _pmask=None):
     """masking.py:71-102.  img [B,C,H,W], mask / rendered_mask [B,1,H,W], extra_points [B,C,H,W] -> masked_img [B,C,H,W].
-    `_noise_mult` ([B,C,H,W]) and `_random_field` ([B,1,H,W] of 0/1 patch centres) override the random draws (tests)."""
-    img, mask, extra_points = L.as_f32c(img), L.as_f32c(mask), L.as_f32c(extra_points)
+    `_noise_mult` ([B,C,H,W]) and `_random_field` ([B,1,H,W] of 0/1 patch centres) override the random draws (tests);
+    `_pmask` ([B,1,H,W]) with extra_points=None fuses the caller's `extra_points = img * pmask` (demo.py:163)."""
+    img, mask = L.as_f32c(img), L.as_f32c(mask)
+    extra_points = None if extra_points is None else L.as_f32c(extra_points)
     B, C, H, W = img.shape
     lib, st = L.lib(), L.stream_ptr()
     if mask.shape[0] != B:
@@ -85,8 +83,9 @@ def masking(img, mask, extra_points, wr=15, rendered_mask=None, extra_noise=True
     out = torch.empty_like(img)
     noise = None if _noise_mult is None else L.as_f32c(_noise_mult)
     seed, off = _rng(img.numel()) if (extra_noise and noise is None) else (0, 0)
-    L.check(lib.smirk_masking_compose(L.ptr(img), L.ptr(mask_d), L.ptr(rm, allow_none=True), L.ptr(extra_points),
-                                      L.ptr(keep, allow_none=True), L.ptr(noise, allow_none=True), B, C, H, W,
+    pm = None if _pmask is None else L.as_f32c(_pmask)
+    L.check(lib.smirk_masking_compose(L.ptr(img), L.ptr(mask_d), L.ptr(rm, allow_none=True), L.ptr(extra_points, allow_none=True),
+                                      L.ptr(pm, allow_none=True), L.ptr(keep, allow_none=True), L.ptr(noise, allow_none=True), B, C, H, W,
                                       int(bool(extra_noise) and noise is None), seed, off, L.ptr(out), st))
     return out
 
@@ -166,3 +165,38 @@ def mesh_based_mask_uniform_faces(flame_trans_verts, flame_faces, face_probabili
     npoints = torch.empty(B, n, 3, dtype=torch.int64, device=dev)
     L.check(lib.smirk_points_to_pixels(L.ptr(pts), B, n, IMAGE_SIZE, L.ptr(npoints, torch.int64), st))
     return npoints, {'sampled_faces_indices': idx.long(), 'barycentric_coords': bary}
+
+
+def rendered_mask_of(rendered_img):
+    """rendered_mask = 1 - (rendered_img == 0).all(dim=1, keepdim=True).float()   (demo.py:146, smirk_trainer.py:79)."""
+    x = L.as_f32c(rendered_img)
+    B, C, H, W = x.shape
+    out = torch.empty(B, 1, H, W, device=x.device)
+    L.check(L.lib().smirk_rendered_mask(L.ptr(x), B, C, H, W, L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def points_mask(npoints, H, W, rbound=None):
+    """pmask[b, :, y, x] = 1 at the first rbound[b] sampled points (demo.py:153-159) -> [B,1,H,W]."""
+    p = npoints.long().contiguous()
+    B, Lp = p.shape[:2]
+    rb = None if rbound is None else rbound.long().contiguous()
+    out = torch.empty(B, 1, H, W, device=p.device)
+    L.check(L.lib().smirk_scatter_points_mask(L.ptr(p, torch.int64), L.ptr(rb, torch.int64, True), B, Lp, H, W, L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def demo_masked_image(img, hull_mask, rendered_img, transformed_vertices, flame_faces, face_probabilities,
+                      mask_ratio=0.01, mask_ratio_mul=5, mask_dilation_radius=10):
+    """The block demo.py:138-165 runs between Renderer and SmirkGenerator, on the GPU: rendered mask, mesh-based point sampling with a
+    random per-image budget, point mask, masking().  Returns masked_img [B,3,H,W]."""
+    B, _, H, W = img.shape
+    rmask = rendered_mask_of(rendered_img)
+    npoints, _ = mesh_based_mask_uniform_faces(transformed_vertices, flame_faces, face_probabilities, mask_ratio=mask_ratio * mask_ratio_mul,
+                                               IMAGE_SIZE=H)
+    g = torch.Generator().manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+    rsing = torch.randint(0, 2, (B,), generator=g) * 2 - 1                                    # demo.py:154-156 (host-side scalars per image)
+    rscale = torch.rand((B,), generator=g) * (mask_ratio_mul - 1) + 1
+    rbound = (npoints.size(1) * (1 / mask_ratio_mul) * (rscale ** rsing)).long().to(img.device)
+    pmask = points_mask(npoints, H, W, rbound)
+    return masking(img, hull_mask, None, mask_dilation_radius, rendered_mask=rmask, _pmask=pmask)

@@ -22,11 +22,19 @@ def shard_bounds(total, rank, world):
 class SmirkPipeline:
     """Holds the four drop-in modules; __call__ runs one batch of frames that are already resident on this GPU."""
 
-    def __init__(self, encoder, flame, renderer, generator=None):
+    def __init__(self, encoder, flame, renderer, generator=None, face_probabilities=None):
         self.encoder, self.flame, self.renderer, self.generator = encoder, flame, renderer, generator
+        self.face_probabilities = face_probabilities      # enables hull_mask= (masking utilities, demo.py:138-165)
+
+    def masked_from_hull(self, img, hull_mask, rn):
+        from . import masking as M
+        if self.face_probabilities is None:
+            raise ValueError("SmirkPipeline(face_probabilities=masking.load_probabilities_per_FLAME_triangle()) is required for hull_mask=")
+        return M.demo_masked_image(img, hull_mask, rn['rendered_img'], rn['transformed_vertices'], self.flame.faces_tensor,
+                                   self.face_probabilities)
 
     @torch.no_grad()
-    def __call__(self, img, masked_img=None, with_landmarks=True):
+    def __call__(self, img, masked_img=None, with_landmarks=True, hull_mask=None):
         enc = self.encoder(img)
         fl = self.flame.forward(enc)
         lm = dict(landmarks_fan=fl['landmarks_fan'], landmarks_mp=fl['landmarks_mp']) if with_landmarks else {}
@@ -34,8 +42,11 @@ class SmirkPipeline:
         out = dict(enc)
         out.update(vertices=fl['vertices'], landmarks_fan_3d=fl['landmarks_fan_3d'], **rn)
         if self.generator is not None:
+            if masked_img is None and hull_mask is not None:
+                masked_img = self.masked_from_hull(img, hull_mask, rn)
+                out['masked_img'] = masked_img
             if masked_img is None:
-                raise ValueError("the generator needs the masked image (utils/masking.py output) next to the rendering")
+                raise ValueError("the generator needs the masked image (or hull_mask=) next to the rendering")
             x = self.generator.pack_input(rn['rendered_img'], masked_img)      # cat + NCHW->NHWC fused
             out['reconstructed_img'] = self.generator.forward_nhwc(x)
         return out
@@ -72,6 +83,10 @@ class OverlappedPipeline:
         with torch.cuda.stream(self.gen_stream):
             self.gen_stream.wait_event(ev)
             g = self.pipe.generator
+            if isinstance(masked, tuple):                   # ("hull", img, hull_mask): masking utilities run with the generator stage
+                _, im, hull = masked
+                masked = self.pipe.masked_from_hull(im, hull, out)
+                out['masked_img'] = masked
             x = g.pack_input(out['rendered_img'], masked)
             out['reconstructed_img'] = g.forward_nhwc(x)
             for t in (out['rendered_img'], masked):
@@ -85,7 +100,7 @@ class OverlappedPipeline:
         return out
 
     @torch.no_grad()
-    def submit(self, img, masked_img, with_landmarks=True):
+    def submit(self, img, masked_img=None, with_landmarks=True, hull_mask=None):
         self._streams(img.device)
         caller = torch.cuda.current_stream()
         ready = torch.cuda.Event()
@@ -103,7 +118,7 @@ class OverlappedPipeline:
             ev = torch.cuda.Event()
             ev.record(self.front_stream)
             img.record_stream(self.front_stream)
-        self._pending = (out, masked_img, ev)
+        self._pending = (out, masked_img if hull_mask is None else ("hull", img, hull_mask), ev)
         return prev
 
     def flush(self):

@@ -49,7 +49,7 @@ def test_face_weights_and_sampler_law(ctx):
     L.check(L.lib().smirk_mask_face_weights(L.ptr(tv), L.ptr(normals), L.ptr(bufs["faces"], torch.int32), L.ptr(prob.cuda()), B, V, F,
                                             L.ptr(w), L.stream_ptr()))
     w = w.cpu().numpy()
-    assert np.array_equal(w > 0, g["weights"] > 0) and np.abs(w - g["weights"]).max() < 1e-7
+    assert np.array_equal(w > 0, g["weights"] > 0) and np.abs(w - g["weights"]).max() < 5e-7       # shoelace cancellation of O(1) products
     # sampler: many draws, chi-square-like check of empirical frequencies against the weights + barycentric validity
     torch.manual_seed(123)
     npts, out = M.mesh_based_mask_uniform_faces(tv, faces, prob, mask_ratio=2.0)       # 100352 draws per image
@@ -99,10 +99,46 @@ def test_masking_and_transfer_match_reference(ctx, sandbox, golden_dir):
     sel = (extra.numpy() > 0) & (o3 == o3)
     ratio = o3[sel] / extra.numpy()[sel]
     kept = ratio > 0.5
-    assert 0.6 < kept.mean() < 0.85                        # ~1 - P(pixel inside an 11x11 patch of a 1 % Bernoulli field) = 0.99^121 ~ 0.30 dropped
+    assert 0.2 < kept.mean() < 0.5                         # P(pixel in no 11x11 patch of a 1 % Bernoulli field) = 0.99^121 ~ 0.30 (more near borders)
     assert abs(ratio[kept].mean() - 1) < 0.01 and 0.035 < ratio[kept].std() < 0.065
     tp = M.transfer_pixels(img.cuda(), npts.cuda(), torch.flip(npts, [1]).cuda()).cpu().numpy()
     assert int((tp != 0).sum()) == int(g["transfer_nonzero"]) and abs(tp.astype(np.float64).sum() - float(g["transfer_sum"])) < 1e-3
     rb = torch.tensor([100, 300])
     tpb = M.transfer_pixels(img.cuda(), npts.cuda(), torch.flip(npts, [1]).cuda(), rbound=rb.cuda()).cpu().numpy()
     assert np.array_equal(tpb, MR.transfer_pixels(img.numpy(), g["npoints"], g["npoints"][:, ::-1], rbound=rb.numpy()))
+
+
+def test_pipeline_with_hull_mask(ctx, sandbox):
+    """SmirkPipeline(hull_mask=...) runs demo.py:138-165 on the GPU between render and generate."""
+    M, prob, g, r, faces = ctx
+    from oracle import generator_ref as G, mobilenet_ref as MB
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator
+    from smirk_amd.pipeline import OverlappedPipeline, SmirkPipeline
+    cwd = os.getcwd(); os.chdir(sandbox)
+    try:
+        fl, rn = FLAME().cuda(), Renderer().cuda()
+    finally:
+        os.chdir(cwd)
+    enc = SmirkEncoder(); enc.load_state_dict(MB.synth_encoder_state_dict()); enc = enc.cuda().eval()
+    gen = SmirkGenerator(6, 3, 32, 5); gen.load_state_dict(G.synth_state_dict()); gen = gen.cuda().eval()
+    pipe = SmirkPipeline(enc, fl, rn, gen, face_probabilities=prob.cuda())
+    img = A.synth_images(3, seed=9).cuda()
+    hull = (A.synth_generator_input(3, seed=9)[:, 3:4] != 0).float().cuda()
+    torch.manual_seed(0)
+    out = pipe(img, hull_mask=hull)
+    mk, rimg = out["masked_img"], out["rendered_img"]
+    assert mk.shape == img.shape and torch.isfinite(out["reconstructed_img"]).all()
+    eroded = 1 - torch.nn.functional.max_pool2d(1 - hull, 21, 1, 10)
+    bg = (eroded == 1) & (rimg[:, :1] == 0)
+    a, b = mk[bg.expand_as(mk)], img[bg.expand_as(img)]                                   # kept photo pixels: untouched, except the few sampled
+    diff = a != b                                                                         # mesh points that fall outside the rendered face region
+    assert diff.float().mean().item() < 0.05 and ((a[diff] / b[diff]) - 1).abs().max().item() < 0.35
+    inside = (rimg[:, :1] != 0).expand_as(mk)
+    frac = (mk[inside] != 0).float().mean().item()
+    assert 0.0 < frac < 0.2                                                               # only the sparse sampled points survive inside the face
+    torch.manual_seed(0)
+    run = OverlappedPipeline(pipe)
+    assert run.submit(img, hull_mask=hull) is None
+    o2 = run.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(o2["masked_img"], mk) and torch.equal(o2["reconstructed_img"], out["reconstructed_img"])
