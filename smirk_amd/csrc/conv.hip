@@ -81,12 +81,15 @@ __device__ __attribute__((aligned(16))) float g_zero16_conv[4] = {0.f, 0.f, 0.f,
 __device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4) ? 2 : 2) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int NW = WGM * WGN, NT = 64 * NW;                 // waves / threads per workgroup (4 or 8 waves)
+    constexpr int RP = NT / 8;                                  // operand rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int PA = BM / RP, PB = BN / RP;
     constexpr int STAGE = (BM + BN) * 32;                       // dwords per pipeline stage
     constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (F16X3 epilogue)
-    static_assert(4 * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
+    static_assert(NW * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile must be a whole number of DMA passes");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int HoWo = d.Ho * d.Wo;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + srow + 32 * p;
+        const int m = m0 + srow + RP * p;
         if (m < a.M) {
             int b, oy, ox;
             row_to_pixel(m, HoWo, d.Wo, a.psh, b, oy, ox);
@@ -146,13 +149,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
             }
             const float* g = ok ? src + ((size_t)(boff[p] + iy * d.W + ix) * cs + cc) : g_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + RP * p) * 32), 16, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int n = n0 + srow + 32 * p;
+            const int n = n0 + srow + RP * p;
             const float* g = (kval && n < a.N) ? a.w + (size_t)n * a.K + k : g_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
         }
     };
 
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int kbase = seg_tap * a.Cin + (seg_src ? d.C0 : 0) + col4 * 4;
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int n = n0 + srow + 32 * p;
+            const int n = n0 + srow + RP * p;
             pb[p] = (n < a.N) ? a.w + (size_t)n * a.K + kbase : g_zero16;
         }
         seg_left = (cs + CV_BK - 1) / CV_BK;
@@ -216,12 +219,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         kleft -= CV_BK;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pa[p] : g_zero16), (lptr_t)(As + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pa[p] : g_zero16), (lptr_t)(As + (wave * 8 + RP * p) * 32), 16, 0, 0);
             pa[p] += inca[p];
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pb[p] : g_zero16), (lptr_t)(Bs + (wave * 8 + 32 * p) * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pb[p] : g_zero16), (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
             pb[p] += (pb[p] == g_zero16) ? 0 : CV_BK;
         }
     };
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
 static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT>), dim3(ntm * ntn), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
 }
 
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
@@ -423,8 +426,12 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
     if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st);
+    static const char* big_env = getenv("SMIRK_IGEMM_8WAVE");
+    const int big = big_env ? atoi(big_env) : 0;                 // tuning switch: 8-wave 128x256 / 256x128 tiles
     if (split) {
-        if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
+        if (big == 1 && a.N >= 256) launch_igemm<128, 256, 2, 4, true>(a, st);
+        else if (big == 2 && a.N >= 128) launch_igemm<256, 128, 4, 2, true>(a, st);
+        else if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
         else launch_igemm<256, 32, 4, 1, true>(a, st);
     } else {
