@@ -159,6 +159,11 @@ int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* 
  * w is [N][K/8][2][8] halves (K ordered (ky,kx,c)), scale / shift stay fp32.  C0, C1, Cout must be multiples of 8. */
 int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
                            const float* scale, const float* shift, const void* residual, void* out, void* stream);
+/* The generator's tail in ONE launch (smirk_generator.py:104-113 dec1conv2+norm2+relu2, :47-49,76 conv + sigmoid): 3x3 conv (zero pad 1, stride 1,
+ * split16 input, Cout = 32) + scale/shift + ReLU + 1x1 conv fw[fcout][32] + fb + sigmoid -> out_nchw[B][fcout][H][W] fp32; the 32-channel
+ * activation never reaches HBM.  Returns SMIRK_ERR_UNSUPPORTED when the shape is not served by the halo-patch kernel (H, W % 16, H >= 64). */
+int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                             const float* shift, const float* fw, const float* fb, float* out_nchw, int fcout, void* stream);
 /* fp32 <-> split16 conversion of n_elems values (n_elems % 8 == 0; groups of 8 consecutive values). */
 int smirk_f32_to_split16(const float* in, void* out, size_t n_elems, void* stream);
 int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, void* stream);

@@ -61,6 +61,7 @@ _SIGS = {
     "smirk_project_landmarks": (_i, [_p, _p, _i, _i, _p, _p]),
     "smirk_conv_igemm_f32": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_conv_igemm_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
+    "smirk_conv3x3_tail_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "smirk_f32_to_split16": (_i, [_p, _p, _sz, _p]),
     "smirk_split16_to_f32": (_i, [_p, _p, _sz, _p]),
     "smirk_maxpool2x2_split16": (_i, [_p, _p, _i, _i, _i, _i, _p]),

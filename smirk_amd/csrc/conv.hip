@@ -395,7 +395,8 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
 bool smirk_conv3x3_patch_eligible(const SmirkConvDesc* d, bool has_residual);
 int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                               const float* shift, void* out, hipStream_t st);
+                               const float* shift, void* out, hipStream_t st, const float* fw, const float* fb, float* fout,
+                               int fcout);
 
 static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                          const float* shift, const void* residual, void* out, void* stream, bool split) {
@@ -425,7 +426,7 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     hipStream_t st = (hipStream_t)stream;
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
     if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
-        return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st);
+        return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
     static const char* big_env = getenv("SMIRK_IGEMM_8WAVE");
     const int big = big_env ? atoi(big_env) : 0;                 // tuning switch: 8-wave 128x256 / 256x128 tiles
     if (split) {
@@ -446,6 +447,16 @@ extern "C" int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, co
                                     const float* scale, const float* shift, const float* residual, float* out,
                                     void* stream) {
     return conv_dispatch(d, in0, in1, w, scale, shift, residual, out, stream, false);
+}
+
+// Network tail in one launch: conv3x3 (split16 in) + BN + ReLU + 1x1 conv (Cout 32 -> fcout <= 4) + bias + sigmoid -> NCHW fp32.
+extern "C" int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                                        const float* shift, const float* fw, const float* fb, float* out_nchw, int fcout,
+                                        void* stream) {
+    if (!d || !in0 || !w || !fw || !out_nchw || fcout <= 0 || fcout > 4 || d->Cout != 32) return SMIRK_ERR_BAD_ARG;
+    if (d->C0 % 8 || d->C1 % 8 || (d->C1 > 0 && !in1) || d->act != SMIRK_ACT_RELU) return SMIRK_ERR_BAD_ARG;
+    if (!smirk_conv3x3_patch_eligible(d, false)) return SMIRK_ERR_UNSUPPORTED;
+    return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, nullptr, (hipStream_t)stream, fw, fb, out_nchw, fcout);
 }
 
 extern "C" int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,

@@ -31,6 +31,11 @@ struct PatchArgs {
     int nchunk;      // 32-channel chunks per patch (over both sources)
     int npatch;      // B * (H/16) * (W/16)
     int act;
+    // optional fused network tail (Cout == 32 only): out_nchw[b][o][y][x] = sigmoid(sum_c relu(bn(conv))[c] * fw[o][c] + fb[o]), o < fcout;
+    // the 32-channel activation is then never written to HBM (smirk_generator.py:47-49,76)
+    const float *fw, *fb;
+    float* fout;
+    int fcout;
 };
 
 __device__ __forceinline__ int lds_piece_p(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
@@ -207,11 +212,34 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                     }
-                    half8 hi, lo;
-                    split8p(v, hi, lo);
-                    float* o = a.out + (((size_t)b * a.H + oy) * a.W + ox) * COUT + g * 8;
-                    *(half8*)o = hi;
-                    *(half8*)(o + 4) = lo;
+                    if (TN == 1 && a.fout) {
+                        // fused 1x1 conv + sigmoid: the 4 lanes e..e+3 hold one pixel's 4 channel groups -> partial dots + 2 xor shuffles
+                        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int o = 0; o < 4; ++o)
+                            if (o < a.fcout) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) part[o] = fmaf(v[q], a.fw[o * COUT + g * 8 + q], part[o]);
+                            }
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            part[o] += __shfl_xor(part[o], 1, 64);
+                            part[o] += __shfl_xor(part[o], 2, 64);
+                        }
+                        if (g == 0) {
+                            const size_t HW = (size_t)a.H * a.W;
+                            for (int o = 0; o < a.fcout; ++o) {
+                                const float z = part[o] + (a.fb ? a.fb[o] : 0.f);
+                                a.fout[((size_t)b * a.fcout + o) * HW + (size_t)oy * a.W + ox] = 1.0f / (1.0f + expf(-z));
+                            }
+                        }
+                    } else {
+                        half8 hi, lo;
+                        split8p(v, hi, lo);
+                        float* o = a.out + (((size_t)b * a.H + oy) * a.W + ox) * COUT + g * 8;
+                        *(half8*)o = hi;
+                        *(half8*)(o + 4) = lo;
+                    }
                 }
                 __syncthreads();
             }
@@ -238,8 +266,10 @@ static bool patch_eligible(const SmirkConvDesc* d, bool has_residual) {
 }
 
 int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                               const float* shift, void* out, hipStream_t st) {
+                               const float* shift, void* out, hipStream_t st, const float* fw, const float* fb, float* fout,
+                               int fcout) {
     PatchArgs a;
+    a.fw = fw; a.fb = fb; a.fout = fout; a.fcout = fcout;
     a.in0 = (const float*)in0; a.in1 = (const float*)in1; a.w = (const float*)w; a.scale = scale; a.shift = shift; a.out = (float*)out;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
     a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;

@@ -187,12 +187,25 @@ class SmirkGenerator(nn.Module):
             b = self._conv(lib, st, y, None, P[f"res{k}b"], B, h16, w16, 16 * f, reflect=True, relu=False, residual=b)
         t["res"] = b
         d = b
+        out = torch.empty(B, self.out_channels, H, W, device=b.device)
+        wf, _, bf = P["final"]
         for lvl, skip, div, c in ((4, e4, 16, 8 * f), (3, e3, 8, 4 * f), (2, e2, 4, 2 * f), (1, e1, 2, f)):
             up = self._conv(lib, st, d, None, P[f"up{lvl}"], B, H // div, W // div, c, k=1, relu=False, convt=True)
+            if lvl == 1 and self._split and taps is None and f == 32 and H % 16 == 0 and W % 16 == 0 and H >= 64:
+                # network tail fused: dec1conv2 + BN + ReLU + final 1x1 conv + sigmoid in one launch, dec1 never written to HBM
+                y = self._conv(lib, st, up, skip, P["dec11"], B, H, W, f)
+                w2, sc2, sh2 = P["dec12"]
+                dd = L.SmirkConvDesc()
+                dd.B, dd.H, dd.W, dd.C0, dd.C1, dd.Cout, dd.KH, dd.KW, dd.stride = B, H, W, f, 0, f, 3, 3, 1
+                dd.pad_t = dd.pad_l = 1
+                dd.Ho, dd.Wo, dd.pad_mode, dd.act, dd.out_mode = H, W, L.PAD_ZERO, L.ACT_RELU, L.OUT_NHWC
+                Pp = L.ptr
+                flops = 2.0 * B * H * W * f * 9 * f
+                L.timed("conv3x3_patch_kernel", flops, lambda: L.check(lib.smirk_conv3x3_tail_f16x3(
+                    dd, Pp(y), None, Pp(w2), Pp(sc2), Pp(sh2), Pp(wf), Pp(bf), Pp(out), self.out_channels, st)))
+                return out
             d = dconv(up, skip, f"dec{lvl}", 2 * H // div, 2 * W // div, c)
             t[f"dec{lvl}"] = d
-        out = torch.empty(B, self.out_channels, H, W, device=d.device)
-        wf, _, bf = P["final"]
         fin = lib.smirk_conv1x1_sigmoid_nchw_split16 if self._split else lib.smirk_conv1x1_sigmoid_nchw
         L.check(fin(L.ptr(d), L.ptr(wf), L.ptr(bf), L.ptr(out), B, H, W, f, self.out_channels, st))
         return out
