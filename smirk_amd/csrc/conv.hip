@@ -39,6 +39,8 @@ struct ConvArgs {
     const float *in0, *in1, *w, *scale, *shift, *residual;   // F16X3: in0/in1/w/residual/out are split-fp16 tensors viewed as dwords
     float* out;
     int M, N, K, Cin;
+    int ablate;    // diagnosis only (SMIRK_IGEMM_ABLATE): bit0 = no operand DMA after the first two chunks, bit1 = no MFMA/LDS reads
+    int mfull;     // conv_igemm_mixed_kernel: number of full-height M tiles (the remaining rows use half-height tiles)
     int psh;       // GEMM rows enumerate each image in (2^psh x 2^psh)-pixel patches (tile-major): a BM-row tile is then a compact 2-D
                    // patch whose 3x3 halo is ~1.3x its area instead of 3 full image rows — the im2col re-reads stay in L1/L2
 };
@@ -74,61 +76,65 @@ __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float
 __device__ __attribute__((aligned(16))) float g_zero16_conv[4] = {0.f, 0.f, 0.f, 0.f};
 #define g_zero16 g_zero16_conv
 
+// branch-free pointer select (hipcc turns `c ? p : q` feeding a DMA into exec-masked branches around each load)
+__device__ __forceinline__ const float* psel(bool c, const float* p, const float* q) {
+    const unsigned long long m = 0ull - (unsigned long long)c;
+    return (const float*)(((unsigned long long)p & m) | ((unsigned long long)q & ~m));
+}
+
 // LDS operand image: [rows][32 dwords] (one 128-byte K chunk per row), written by global_load_lds_dwordx4 — 64 lanes x 16 B =
 // 8 consecutive rows per wave instruction, lane-linear, so no padding is possible.  Bank conflicts are removed by an XOR
 // swizzle applied on the SOURCE side (which 16-byte piece of the row a lane fetches) and on the read side:
 // physical piece = logical piece ^ ((row >> 1) & 7)  => the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte slots.
 __device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
 
-template <int BM, int BN, int WGM, int WGN, bool SPLIT>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4) ? 2 : 2) void conv_igemm_kernel(ConvArgs a) {
+// K-walk modes of conv_tile
+//   KW_GENERIC  any geometry: tap / channel / source recomputed per chunk with divides (3x3 with C % 32 != 0, e.g. an 8-channel input)
+//   KW_FAST     every source has C % 32 == 0: a chunk never straddles a tap or a concat source; im2col pointers are set up once per
+//               (tap, source) SEGMENT and advance by 128 bytes per chunk
+//   KW_FAST_KT  1x1 convolutions with any C % 4 == 0 (the encoders' pointwise layers): one segment per source whose last chunk is
+//               partial — lanes whose 16-byte piece lies beyond the segment read the zero page
+enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2 };
+
+// one BM x BN output tile at (m0, n0); `smem` holds 2 pipeline stages of (BM + BN) x 32 dwords
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const int m0, const int n0) {
     constexpr int NW = WGM * WGN, NT = 64 * NW;                 // waves / threads per workgroup (4 or 8 waves)
     constexpr int RP = NT / 8;                                  // operand rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int PA = BM / RP, PB = BN / RP;
     constexpr int STAGE = (BM + BN) * 32;                       // dwords per pipeline stage
-    constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (F16X3 epilogue)
+    constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (vector epilogue)
     static_assert(NW * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
     static_assert(BM % RP == 0 && BN % RP == 0, "tile must be a whole number of DMA passes");
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const SmirkConvDesc& d = a.d;
 
-    // ---- XCD-aware tile id: hardware places block id on XCD id%8; give each XCD a contiguous run of logical tiles ----
-    const int ntn = (a.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
-    int logical;
-    {
-        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-        const int q = nblk >> 3, r = nblk & 7;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int m0 = (logical / ntn) * BM, n0 = (logical % ntn) * BN;
-
-    // ---- per-thread staging coordinates: thread (srow, pos) fills LDS row srow+32p, physical piece pos ----------------------
+    // ---- per-thread staging coordinates: thread (srow, pos) fills LDS row srow + RP*p, physical piece pos -------------------------
     const int pos = tid & 7, srow = tid >> 3;
     const int col4 = pos ^ ((srow >> 1) & 7);                   // logical 16-byte piece this lane fetches (source-side swizzle)
-    int iy0[PA], ix0[PA], boff[PA];
+    int pyx[PA], boff[PA];                                      // (iy0 << 16 | ix0 & 0xffff) and image offset of each staged row
     const int HoWo = d.Ho * d.Wo;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + srow + RP * p;
-        if (m < a.M) {
-            int b, oy, ox;
-            row_to_pixel(m, HoWo, d.Wo, a.psh, b, oy, ox);
-            iy0[p] = oy * d.stride - d.pad_t;
-            ix0[p] = ox * d.stride - d.pad_l;
-            boff[p] = b * d.H * d.W;
-        } else {
-            iy0[p] = -(1 << 28); ix0[p] = 0; boff[p] = 0;      // out of range => always zero-filled (never reflected: guarded below)
-        }
+        // rows beyond M (ragged last tile) are clamped to the last valid row: they compute garbage that the epilogue never stores,
+        // and no per-load predicate is needed for them
+        const int m = min(m0 + srow + RP * p, a.M - 1);
+        int b, oy, ox;
+        row_to_pixel(m, HoWo, d.Wo, a.psh, b, oy, ox);
+        pyx[p] = ((oy * d.stride - d.pad_t) << 16) | ((ox * d.stride - d.pad_l) & 0xffff);
+        boff[p] = b * d.H * d.W;
     }
+    unsigned wrow[PB];                                          // dword offset of weight row min(n0+srow+RP*p, N-1) (columns beyond N: clamped, never stored)
+#pragma unroll
+    for (int p = 0; p < PB; ++p) wrow[p] = (unsigned)min(n0 + srow + RP * p, a.N - 1) * (unsigned)a.K;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // issue the direct-to-LDS loads of K chunk k0 into pipeline stage `st` (PA + PB instructions per wave, 1 KiB each)
-    auto issue_chunk = [&](int k0, int st) {
+
+    // ---- KW_GENERIC: issue the direct-to-LDS loads of K chunk k0 into pipeline stage `st` ------------------------------------------
+    auto issue_generic = [&](int k0, int st) {
         float* As = smem + st * STAGE;
         float* Bs = As + BM * 32;
         const int k = k0 + col4 * 4;
@@ -141,22 +147,66 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4) ? 2 : 2) void conv_
         const int cs = src1 ? d.C1 : d.C0, cc = src1 ? c - d.C0 : c;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            int iy = iy0[p] + ky, ix = ix0[p] + kx;
-            bool ok = kval && (iy0[p] > -(1 << 27));
-            if (d.pad_mode == SMIRK_PAD_REFLECT) {
-                if (ok) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); }
-            } else {
-                ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-            }
-            const float* g = ok ? src + ((size_t)(boff[p] + iy * d.W + ix) * cs + cc) : g_zero16;
+            int iy = (pyx[p] >> 16) + ky, ix = (int)(short)(pyx[p] & 0xffff) + kx;
+            bool ok = kval;
+            if (d.pad_mode == SMIRK_PAD_REFLECT) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); }
+            else ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            iy = min(max(iy, 0), d.H - 1); ix = min(max(ix, 0), d.W - 1);
+            const float* g = psel(ok, src + ((size_t)(boff[p] + iy * d.W + ix) * cs + cc), g_zero16);
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + RP * p) * 32), 16, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int n = n0 + srow + RP * p;
-            const float* g = (kval && n < a.N) ? a.w + (size_t)n * a.K + k : g_zero16;
+            const float* g = psel(kval, a.w + wrow[p] + k, g_zero16);
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
         }
+    };
+
+    // ---- KW_FAST*: segment state ------------------------------------------------------------------------------------------------------
+    const float* pa[PA];
+    int inca[PA];                                               // 32 dwords, or 0 when the row reads the zero page
+    const float* pbase = a.w;                                   // a.w + k offset of the next chunk to issue (this lane's piece)
+    int seg_left = 0, seg_tap = 0, seg_src = 0;                 // chunks left to ISSUE in the open segment; next segment to open
+    int kleft = 0;                                              // KW_FAST_KT: dwords of the segment still ahead of this lane's piece
+    auto open_segment = [&]() {
+        const int ky = seg_tap / d.KW, kx = seg_tap - ky * d.KW;
+        const float* src = seg_src ? a.in1 : a.in0;
+        const int cs = seg_src ? d.C1 : d.C0;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int iy = (pyx[p] >> 16) + ky, ix = (int)(short)(pyx[p] & 0xffff) + kx;
+            bool ok = true;
+            if (d.pad_mode == SMIRK_PAD_REFLECT) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); }
+            else ok = iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            iy = min(max(iy, 0), d.H - 1); ix = min(max(ix, 0), d.W - 1);
+            pa[p] = psel(ok, src + ((size_t)(boff[p] + iy * d.W + ix) * cs + col4 * 4), g_zero16);
+            inca[p] = ok ? CV_BK : 0;
+        }
+        pbase = a.w + (seg_tap * a.Cin + (seg_src ? d.C0 : 0) + col4 * 4);
+        seg_left = (cs + CV_BK - 1) / CV_BK;
+        kleft = cs - col4 * 4;
+        if (d.C1 > 0 && seg_src == 0) seg_src = 1; else { seg_src = 0; ++seg_tap; }
+    };
+    // straight-line (branch-free) issue of the next chunk: 1 KiB DMA per wave instruction + pointer bumps; meant to sit in the same basic
+    // block as the MFMAs of the current chunk so the scheduler can hide it in their shadow
+    auto issue_fast = [&](int st) {
+        float* As = smem + st * STAGE;
+        float* Bs = As + BM * 32;
+        const bool kv = (KWALK == KW_FAST_KT) ? (kleft > 0) : true;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const float* g = (KWALK == KW_FAST_KT) ? psel(kv, pa[p], g_zero16) : pa[p];
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + RP * p) * 32), 16, 0, 0);
+            pa[p] += inca[p];
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const float* g = (KWALK == KW_FAST_KT) ? psel(kv, pbase + wrow[p], g_zero16) : pbase + wrow[p];
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
+        }
+        pbase += CV_BK;
+        kleft -= CV_BK;
+        --seg_left;
     };
 
     constexpr int NACC = SPLIT ? 2 : 1;
@@ -170,101 +220,35 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4) ? 2 : 2) void conv_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
-    const int nchunk = (a.K + CV_BK - 1) / CV_BK;
     const int fr = lane & 31, hb = lane >> 5;
-
-    // ---- fast K walk (every source has C % 32 == 0, i.e. all generator layers but the first): a K chunk never straddles a tap or
-    // a concat source, so the im2col pointers are set up once per (tap, source) SEGMENT and then just advance by 128 bytes per
-    // chunk; the per-chunk cost is PA+PB pointer bumps instead of a divide + bounds/reflect + 64-bit address rebuild per row.
-    // 1x1 convolutions (the encoders' pointwise layers, any C % 4 == 0) take the same path: one segment per source whose last chunk is
-    // partial — lanes whose 16-byte piece lies beyond the segment read the zero page.
-    const bool fastk = ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) || (d.KH * d.KW == 1);
-    const float* pa[PA];
-    const float* pb[PB];
-    int inca[PA];                                               // 32 dwords, or 0 when the row reads the zero page
-    int seg_left = 0, seg_tap = 0, seg_src = 0;                 // chunks left in the current segment; next segment to open
-    int kleft = 0;                                              // dwords of the segment still ahead of this lane's piece (<= 0: zero-fill)
-    auto open_segment = [&]() {
-        const int ky = seg_tap / d.KW, kx = seg_tap - ky * d.KW;
-        const float* src = seg_src ? a.in1 : a.in0;
-        const int cs = seg_src ? d.C1 : d.C0;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            int iy = iy0[p] + ky, ix = ix0[p] + kx;
-            bool ok = iy0[p] > -(1 << 27);
-            if (d.pad_mode == SMIRK_PAD_REFLECT) {
-                if (ok) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); }
-            } else {
-                ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-            }
-            pa[p] = ok ? src + ((size_t)(boff[p] + iy * d.W + ix) * cs + col4 * 4) : g_zero16;
-            inca[p] = ok ? CV_BK : 0;
-        }
-        const int kbase = seg_tap * a.Cin + (seg_src ? d.C0 : 0) + col4 * 4;
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int n = n0 + srow + RP * p;
-            pb[p] = (n < a.N) ? a.w + (size_t)n * a.K + kbase : g_zero16;
-        }
-        seg_left = (cs + CV_BK - 1) / CV_BK;
-        kleft = cs - col4 * 4;
-        if (d.C1 > 0 && seg_src == 0) seg_src = 1; else { seg_src = 0; ++seg_tap; }
-    };
-    auto issue_fast = [&](int st) {
-        float* As = smem + st * STAGE;
-        float* Bs = As + BM * 32;
-        if (seg_left == 0) open_segment();
-        --seg_left;
-        const bool kv = kleft > 0;
-        kleft -= CV_BK;
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pa[p] : g_zero16), (lptr_t)(As + (wave * 8 + RP * p) * 32), 16, 0, 0);
-            pa[p] += inca[p];
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(kv ? pb[p] : g_zero16), (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
-            pb[p] += (pb[p] == g_zero16) ? 0 : CV_BK;
-        }
-    };
-    if (fastk) issue_fast(0); else issue_chunk(0, 0);
-    const int nloop = fastk ? d.KH * d.KW * ((d.C0 + CV_BK - 1) / CV_BK + (d.C1 + CV_BK - 1) / CV_BK) : nchunk;
-    for (int ch = 0; ch < nloop; ++ch) {
-        // chunk ch has landed in LDS once THIS wave's loads retire and every wave has passed the barrier; the barrier also means
-        // every wave finished reading stage (ch+1)&1 (used by chunk ch-1), so it may be refilled right away, under the MFMAs.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
-        if (ch + 1 < nloop) {
-            if (fastk) issue_fast((ch + 1) & 1); else issue_chunk((ch + 1) * CV_BK, (ch + 1) & 1);
-        }
-        const float* As = smem + (ch & 1) * STAGE;
-        const float* Bs = As + BM * 32;
+    // all LDS operand reads of a chunk (both 16-k steps) go out up front into two fragment sets, then the MFMAs
+    auto compute = [&](const float* As, const float* Bs) {
         if constexpr (SPLIT) {
+            half8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-            for (int s = 0; s < CV_BK / 16; ++s) {               // one 16-k MFMA step: lanes 0-31 group 2s, lanes 32-63 group 2s+1
+            for (int s = 0; s < 2; ++s) {
                 const int pc = 2 * (2 * s + hb);                  // logical piece of this lane's hi halves (lo = pc + 1)
-                half8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = (wm * TM + i) * 32 + fr;
-                    ah[i] = *(const half8*)(As + lds_piece(row, pc)); al[i] = *(const half8*)(As + lds_piece(row, pc + 1));
+                    ah[s][i] = *(const half8*)(As + lds_piece(row, pc)); al[s][i] = *(const half8*)(As + lds_piece(row, pc + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = (wn * TN + j) * 32 + fr;
-                    bh[j] = *(const half8*)(Bs + lds_piece(row, pc)); bl[j] = *(const half8*)(Bs + lds_piece(row, pc + 1));
+                    bh[s][j] = *(const half8*)(Bs + lds_piece(row, pc)); bl[s][j] = *(const half8*)(Bs + lds_piece(row, pc + 1));
                 }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[0][i][j], 0, 0, 0);
-                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[NACC - 1][i][j], 0, 0, 0);
-                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[NACC - 1][i][j], 0, 0, 0);
-                    }
             }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[0][i][j], 0, 0, 0);
+                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[NACC - 1][i][j], 0, 0, 0);
+                        acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[NACC - 1][i][j], 0, 0, 0);
+                    }
         } else {
 #pragma unroll
             for (int kk = 0; kk < CV_BK / 8; ++kk) {
@@ -282,6 +266,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4) ? 2 : 2) void conv_
                             acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[0][i][j], 0, 0, 0);
             }
         }
+    };
+    auto chunk_ready = [&]() {
+        // chunk data has landed once THIS wave's DMAs retire and every wave has passed the barrier; the barrier also means every wave
+        // finished reading the other stage (used by the previous chunk), so it may be refilled right away, under the MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
+    };
+
+    if constexpr (KWALK == KW_GENERIC) {
+        const int nchunk = (a.K + CV_BK - 1) / CV_BK;
+        issue_generic(0, 0);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            chunk_ready();
+            if (ch + 1 < nchunk) issue_generic((ch + 1) * CV_BK, (ch + 1) & 1);
+            compute(smem + (ch & 1) * STAGE, smem + (ch & 1) * STAGE + BM * 32);
+        }
+    } else {
+        const int nloop = d.KH * d.KW * ((d.C0 + CV_BK - 1) / CV_BK + (d.C1 + CV_BK - 1) / CV_BK);
+        open_segment();
+        issue_fast(0);
+        for (int ch = 0; ch + 1 < nloop; ++ch) {                 // every iteration issues the NEXT chunk: no guard inside the hot block
+            if (seg_left == 0) open_segment();                   // rare (once per tap / source), before the hot block
+            chunk_ready();
+            const float* As = smem + (ch & 1) * STAGE;
+            issue_fast((ch + 1) & 1);
+            compute(As, As + BM * 32);
+        }
+        chunk_ready();
+        compute(smem + ((nloop - 1) & 1) * STAGE, smem + ((nloop - 1) & 1) * STAGE + BM * 32);
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------
@@ -386,10 +400,73 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4) ? 2 : 2) void conv_
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SPLIT>
-static void launch_igemm(const ConvArgs& a, hipStream_t st) {
+// XCD-aware tile id: hardware places block id on XCD id%8; give each XCD a contiguous run of logical tiles
+__device__ __forceinline__ int xcd_logical(int id, int nblk) {
+    const int xcd = id & 7, slot = id >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+__global__ __launch_bounds__(64 * WGM * WGN, (BM * BN == 128 * 128 && WGM * WGN == 8) ? 4 : 2) void conv_igemm_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
+    const int ntn = (a.N + BN - 1) / BN;
+    const int logical = xcd_logical(blockIdx.x, gridDim.x);
+    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, (logical / ntn) * BM, (logical % ntn) * BN);
+}
+
+// Tail balancing.  When the tile count leaves a short last round (e.g. 784 tiles on 512 resident slots), the first a.mfull M-tiles are
+// full BM x BN tiles and the rest of M is cut into BM/2 x BN tiles launched AFTER them in the same grid: the last round then takes half
+// the time (1.5 instead of 2 rounds for the 14x14 layers).  Results are identical — every output element still sees the same K order.
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_mixed_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
+    const int ntn = (a.N + BN - 1) / BN;
+    const int nfull = a.mfull * ntn;
+    if ((int)blockIdx.x < nfull) {
+        const int logical = xcd_logical(blockIdx.x, nfull);
+        conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, (logical / ntn) * BM, (logical % ntn) * BN);
+    } else {
+        const int logical = xcd_logical(blockIdx.x - nfull, gridDim.x - nfull);
+        conv_tile<BM / 2, BN, WGM, WGN, SPLIT, KWALK>(a, smem, a.mfull * BM + (logical / ntn) * (BM / 2), (logical % ntn) * BN);
+    }
+}
+
+static int resident_slots() {                                    // 2 workgroups per CU for the 128x128 tile (LDS 2 x 64 KiB, <= 256 VGPRs)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    return slots;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+static void launch_igemm_kw(ConvArgs a, hipStream_t st, bool balance_tail) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
+    if constexpr (BM / WGM >= 64 && WGM * WGN == 4) {
+        if (balance_tail) {
+            const int slots = resident_slots(), total = ntm * ntn;
+            const int rounds = total / slots, rem = total - rounds * slots;
+            // worth it when the last round is at most 3/4 full and there is at least one full round before it
+            if (rounds >= 1 && rem > 0 && 4 * rem <= 3 * slots && slots % ntn == 0) {
+                a.mfull = rounds * slots / ntn;
+                const int nhalf = (a.M - a.mfull * BM + BM / 2 - 1) / (BM / 2) * ntn;
+                hipLaunchKernelGGL((conv_igemm_mixed_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(a.mfull * ntn + nhalf), dim3(64 * WGM * WGN), 0, st, a);
+                return;
+            }
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool SPLIT>
+static void launch_igemm(const ConvArgs& a, hipStream_t st, bool balance_tail = false) {
+    const SmirkConvDesc& d = a.d;
+    if ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST>(a, st, balance_tail);
+    else if (d.KH * d.KW == 1) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST_KT>(a, st, balance_tail);
+    else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC>(a, st, balance_tail);
 }
 
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
@@ -420,6 +497,8 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     const long long M = (long long)d->B * d->Ho * d->Wo;
     if (M > (1ll << 30) || (long long)d->B * d->H * d->W > (1ll << 30)) return SMIRK_ERR_UNSUPPORTED;
     a.M = (int)M;
+    a.ablate = 0;
+    a.mfull = 0;
     a.psh = 0;
     if (d->KH == 3)                                             // only convs with a halo profit from patch ordering
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
@@ -432,7 +511,8 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     if (split) {
         if (big == 1 && a.N >= 256) launch_igemm<128, 256, 2, 4, true>(a, st);
         else if (big == 2 && a.N >= 128) launch_igemm<256, 128, 4, 2, true>(a, st);
-        else if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
+        else if (big == 3 && a.N >= 128) launch_igemm<128, 128, 2, 4, true>(a, st);      // 8 waves of 64x32: more waves per SIMD
+        else if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st, getenv("SMIRK_TAIL_BALANCE") != nullptr);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
         else launch_igemm<256, 32, 4, 1, true>(a, st);
     } else {
