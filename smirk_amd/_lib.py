@@ -74,6 +74,9 @@ _SIGS = {
     "smirk_stem_conv_s2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_dwconv3x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smirk_gap_linear": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_stem_conv_s2_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_dwconv3x3_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "smirk_gap_linear_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_expression_clamps": (_i, [_p, _i, _i, _p]),
 }
 EXPORTS = tuple(_SIGS)

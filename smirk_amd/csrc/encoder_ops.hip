@@ -5,6 +5,18 @@
 // Bound: HBM (each activation read once, written once).
 #include "common.h"
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// split-fp16 activation format (see conv.hip): 8 channels = 8 hi halves + 8 lo halves; value = hi + lo * 2^-11
+__device__ __forceinline__ void enc_split8(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const _Float16 h = (_Float16)v[q];
+        hi[q] = h;
+        lo[q] = (_Float16)((v[q] - (float)h) * 2048.0f);
+    }
+}
+__device__ __forceinline__ float enc_join(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
+
 // TF 'SAME' leading pad for kernel 3: total = max((ceil(n/s)-1)*s + 3 - n, 0); leading = total/2
 __host__ __device__ static inline int same_pad_lead(int n, int s) {
     const int o = (n + s - 1) / s;
@@ -15,7 +27,7 @@ __host__ __device__ static inline int same_pad_lead(int n, int s) {
 
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        float* __restrict__ out, int B, int H, int W, int Cout) {
+                                                        float* __restrict__ out, int B, int H, int W, int Cout, int split) {
     extern __shared__ float sw[];   // [27][Cout] transposed weights, then scale[Cout], shift[Cout]
     for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) { const int k = i / Cout, co = i % Cout; sw[i] = w[co * 27 + k]; }
     for (int i = threadIdx.x; i < Cout; i += blockDim.x) { sw[27 * Cout + i] = scale[i]; sw[28 * Cout + i] = shift[i]; }
@@ -37,27 +49,43 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                 for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? img[(b * 3 + c) * HW + (size_t)iy * W + ix] : 0.f;
             }
         float* o = out + i * Cout;
-        for (int co = 0; co < Cout; co += 4) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int co = 0; co < Cout; co += 8) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 27; ++k)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(x[k], sw[k * Cout + co + q], acc[q]);
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(x[k], sw[k * Cout + co + q], acc[q]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = fmaxf(acc[q] * sw[27 * Cout + co + q] + sw[28 * Cout + co + q], 0.f);
-            *(f32x4*)(o + co) = acc;
+            for (int q = 0; q < 8; ++q) acc[q] = fmaxf(acc[q] * sw[27 * Cout + co + q] + sw[28 * Cout + co + q], 0.f);
+            if (split) {
+                half8 hi, lo;
+                enc_split8(acc, hi, lo);
+                *(half8*)(o + co) = hi;
+                *(half8*)(o + co + 4) = lo;
+            } else {
+                *(f32x4*)(o + co) = *(f32x4*)acc;
+                *(f32x4*)(o + co + 4) = *(f32x4*)(acc + 4);
+            }
         }
     }
 }
 
-extern "C" int smirk_stem_conv_s2(const float* img, const float* w, const float* scale, const float* shift, float* out,
-                                  int B, int H, int W, int Cout, void* stream) {
-    if (!img || !w || !scale || !shift || !out || B <= 0 || Cout % 4 || Cout <= 0 || Cout > 64) return SMIRK_ERR_BAD_ARG;
+static int stem_launch(const float* img, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
+                       int Cout, void* stream, int split) {
+    if (!img || !w || !scale || !shift || !out || B <= 0 || Cout % 8 || Cout <= 0 || Cout > 64) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), (size_t)29 * Cout * 4, (hipStream_t)stream, img, w, scale,
-                       shift, out, B, H, W, Cout);
+                       shift, out, B, H, W, Cout, split);
     return smirk_launch_status();
+}
+extern "C" int smirk_stem_conv_s2(const float* img, const float* w, const float* scale, const float* shift, float* out,
+                                  int B, int H, int W, int Cout, void* stream) {
+    return stem_launch(img, w, scale, shift, out, B, H, W, Cout, stream, 0);
+}
+extern "C" int smirk_stem_conv_s2_split16(const float* img, const float* w, const float* scale, const float* shift, void* out,
+                                          int B, int H, int W, int Cout, void* stream) {
+    return stem_launch(img, w, scale, shift, (float*)out, B, H, W, Cout, stream, 1);
 }
 
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const f32x4* __restrict__ in, const f32x4* __restrict__ w,
@@ -98,6 +126,63 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const f32x4* __restrict_
     }
 }
 
+// depthwise 3x3 on split16 activations: one lane = one pixel x one 8-channel group (32 bytes in, 32 bytes out), fp32 arithmetic
+__global__ __launch_bounds__(256) void dwconv3x3_split_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ out, int B, int H, int W, int G, int stride,
+                                                              int relu) {
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const int pt = stride == 1 ? 1 : same_pad_lead(H, stride), pl = stride == 1 ? 1 : same_pad_lead(W, stride);
+    const int C = G * 8;
+    const size_t total = (size_t)B * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const size_t b = t / Ho;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - pt + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - pl + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float* p = in + (((b * H + iy) * W + ix) * G + g) * 8;
+                const half8 hi = *(const half8*)p, lo = *(const half8*)(p + 4);
+                const float* ww = w + (ky * 3 + kx) * C + g * 8;
+                const f32x4 w0 = *(const f32x4*)ww, w1 = *(const f32x4*)(ww + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = fmaf(enc_join(hi[q], lo[q]), w0[q], acc[q]);
+                    acc[4 + q] = fmaf(enc_join(hi[4 + q], lo[4 + q]), w1[q], acc[4 + q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float v = acc[q] * scale[g * 8 + q] + shift[g * 8 + q];
+            acc[q] = relu ? fmaxf(v, 0.f) : v;
+        }
+        half8 hi, lo;
+        enc_split8(acc, hi, lo);
+        *(half8*)(out + i * 8) = hi;
+        *(half8*)(out + i * 8 + 4) = lo;
+    }
+}
+
+extern "C" int smirk_dwconv3x3_split16(const void* in, const float* w, const float* scale, const float* shift, void* out, int B,
+                                       int H, int W, int C, int stride, int relu, void* stream) {
+    if (!in || !w || !scale || !shift || !out || B <= 0 || C % 8 || C <= 0 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
+    const size_t total = (size_t)B * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(dwconv3x3_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, w, scale, shift,
+                       (float*)out, B, H, W, C / 8, stride, relu);
+    return smirk_launch_status();
+}
+
 extern "C" int smirk_dwconv3x3(const float* in, const float* w, const float* scale, const float* shift, float* out, int B,
                                int H, int W, int C, int stride, int relu, void* stream) {
     if (!in || !w || !scale || !shift || !out || B <= 0 || C % 4 || C <= 0 || (stride != 1 && stride != 2))
@@ -114,13 +199,19 @@ extern "C" int smirk_dwconv3x3(const float* in, const float* w, const float* sca
 // with a shuffle reduction — 5 x more workgroups than one-per-face for the 300-wide shape head, which was latency-bound.
 __global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int HW,
-                                                         int C, int N) {
+                                                         int C, int N, int split) {
     extern __shared__ float pooled[];
     const int b = blockIdx.y, n_lo = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* f = feat + (size_t)b * HW * C;
     for (int c = tid; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += f[(size_t)p * C + c];
+        if (split) {
+            const _Float16* h = (const _Float16*)f;
+            const int off = (c >> 3) * 16 + (c & 7);                    // halves: group base + hi lane; lo is 8 halves further
+            for (int p = 0; p < HW; ++p) s += enc_join(h[(size_t)p * C * 2 + off], h[(size_t)p * C * 2 + off + 8]);
+        } else {
+            for (int p = 0; p < HW; ++p) s += f[(size_t)p * C + c];
+        }
         pooled[c] = s / (float)HW;
     }
     __syncthreads();
@@ -135,12 +226,19 @@ __global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict
     }
 }
 
+static int gap_launch(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C, int N, void* stream, int split) {
+    if (!feat || !w || !out || B <= 0 || HW <= 0 || C <= 0 || N <= 0 || C > 8192 || (split && C % 8)) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gap_linear_kernel, dim3((N + 63) / 64, B), dim3(256), (size_t)C * 4, (hipStream_t)stream, feat, w, bias, out,
+                       HW, C, N, split);
+    return smirk_launch_status();
+}
 extern "C" int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C,
                                 int N, void* stream) {
-    if (!feat || !w || !out || B <= 0 || HW <= 0 || C <= 0 || N <= 0 || C > 8192) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gap_linear_kernel, dim3((N + 63) / 64, B), dim3(256), (size_t)C * 4, (hipStream_t)stream, feat, w, bias, out,
-                       HW, C, N);
-    return smirk_launch_status();
+    return gap_launch(feat, w, bias, out, B, HW, C, N, stream, 0);
+}
+extern "C" int smirk_gap_linear_split16(const void* feat, const float* w, const float* bias, float* out, int B, int HW, int C,
+                                        int N, void* stream) {
+    return gap_launch((const float*)feat, w, bias, out, B, HW, C, N, stream, 1);
 }
 
 __global__ void expression_clamps_kernel(float* __restrict__ p, int B, int n_exp) {

@@ -16,6 +16,9 @@ import torch.nn as nn
 from . import _lib as L
 
 BN_EPS = 1e-3   # "tf_" models
+# arithmetic of the pointwise convolutions: "f16x3" = split-fp16 MFMA (fp32-class accuracy at the 16-bit matrix rate, activations kept in
+# the split16 format through the whole backbone), "f32" = exact fp32 MFMA.  See smirk_generator.py / conv.hip.
+PRECISION = os.environ.get("SMIRK_AMD_ENCODER_PRECISION", "f16x3")
 _STREAMS = {}   # per-device side streams of SmirkEncoder.forward (kept off the module so copy.deepcopy(encoder) keeps working)
 
 _ARCH = {
@@ -95,9 +98,10 @@ class MobileNetV3Features(nn.Module):
         self.feature_info = [dict(num_chs=cin)]      # only [-1]['num_chs'] is consulted (smirk_encoder.py:11)
         self.num_features = cin
         self._packed, self._packed_key = None, None
+        self._split = False
 
     def _key(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        return (PRECISION,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     @staticmethod
     def _affine(bn):
@@ -108,7 +112,11 @@ class MobileNetV3Features(nn.Module):
         key = self._key()
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        pw = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, conv.in_channels).contiguous()
+        from .smirk_generator import _split16
+        split = PRECISION == "f16x3"
+        self._split = split
+        pw32 = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, conv.in_channels).contiguous()
+        pw = (lambda conv: _split16(pw32(conv))) if split else pw32
         dw = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, 9).t().contiguous()      # [9][C]
         P = {"stem": (self.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(16, 27).contiguous(),) + self._affine(self.bn1)}
         for si, st in enumerate(self.blocks):
@@ -124,8 +132,7 @@ class MobileNetV3Features(nn.Module):
         self._packed, self._packed_key = P, key
         return P
 
-    @staticmethod
-    def _pointwise(lib, st, x, pk, relu, residual=None):
+    def _pointwise(self, lib, st, x, pk, relu, residual=None):
         w, sc, sh = pk
         B, H, W, C = x.shape
         d = L.SmirkConvDesc()
@@ -136,21 +143,22 @@ class MobileNetV3Features(nn.Module):
         d.act, d.out_mode = (L.ACT_RELU if relu else L.ACT_NONE), L.OUT_NHWC
         out = torch.empty(B, H, W, w.shape[0], device=x.device)
         P = L.ptr
-        L.timed(L.igemm_kernel_name(w.shape[0]), 2.0 * B * H * W * w.shape[0] * C, lambda: L.check(lib.smirk_conv_igemm_f32(
+        fn = lib.smirk_conv_igemm_f16x3 if self._split else lib.smirk_conv_igemm_f32
+        L.timed(L.igemm_kernel_name(w.shape[0], self._split), 2.0 * B * H * W * w.shape[0] * C, lambda: L.check(fn(
             d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st)))
         return out
 
-    @staticmethod
-    def _depthwise(lib, st, x, pk, stride):
+    def _depthwise(self, lib, st, x, pk, stride):
         w, sc, sh = pk
         B, H, W, C = x.shape
         out = torch.empty(B, (H + stride - 1) // stride, (W + stride - 1) // stride, C, device=x.device)
         P = L.ptr
-        L.check(lib.smirk_dwconv3x3(P(x), P(w), P(sc), P(sh), P(out), B, H, W, C, stride, 1, st))
+        L.check((lib.smirk_dwconv3x3_split16 if self._split else lib.smirk_dwconv3x3)(P(x), P(w), P(sc), P(sh), P(out), B, H, W, C, stride, 1, st))
         return out
 
     def forward(self, img):
-        """img [B,3,H,W] NCHW in [0,1] -> last feature map NHWC [B,H/32,W/32,C]."""
+        """img [B,3,H,W] NCHW in [0,1] -> last feature map NHWC [B,H/32,W/32,C] (fp32, or split16 storage when PRECISION == "f16x3":
+        see `features_f32`)."""
         if self.training:
             raise NotImplementedError("smirk_amd encoders implement the eval-mode forward only (call .eval())")
         lib, st, P = L.lib(), L.stream_ptr(), self._pack()
@@ -158,7 +166,7 @@ class MobileNetV3Features(nn.Module):
         B, _, H, W = img.shape
         w, sc, sh = P["stem"]
         x = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 16, device=img.device)
-        L.check(lib.smirk_stem_conv_s2(L.ptr(img), L.ptr(w), L.ptr(sc), L.ptr(sh), L.ptr(x), B, H, W, 16, st))
+        L.check((lib.smirk_stem_conv_s2_split16 if self._split else lib.smirk_stem_conv_s2)(L.ptr(img), L.ptr(w), L.ptr(sc), L.ptr(sh), L.ptr(x), B, H, W, 16, st))
         for si, stg in enumerate(self.blocks):
             for bi, blk in enumerate(stg):
                 pk = P[(si, bi)]
@@ -174,6 +182,14 @@ class MobileNetV3Features(nn.Module):
         return x
 
 
+def features_f32(backbone, feat):
+    """fp32 NHWC values of a backbone's output feature map (decodes the split16 storage of the f16x3 mode; test helper)."""
+    if getattr(backbone, "_split", False):
+        from .smirk_generator import split16_to_float
+        return split16_to_float(feat)
+    return feat
+
+
 def create_backbone(backbone_name, pretrained=True):
     """smirk_encoder.py:7-12.  `pretrained` is accepted for signature compatibility; weights always come from the checkpoint
     the caller loads next (demo.py:55-58) — there is no download path."""
@@ -181,12 +197,13 @@ def create_backbone(backbone_name, pretrained=True):
     return backbone, backbone.feature_info[-1]['num_chs']
 
 
-def _head(lib, feat, lin):
+def _head(lib, feat, lin, split=False):
     B, h, w, C = feat.shape
     W_ = lin.weight.detach().float().contiguous()
     b_ = lin.bias.detach().float().contiguous()
     out = torch.empty(B, W_.shape[0], device=feat.device)
-    L.check(lib.smirk_gap_linear(L.ptr(feat), L.ptr(W_), L.ptr(b_), L.ptr(out), B, h * w, C, W_.shape[0], L.stream_ptr()))
+    fn = lib.smirk_gap_linear_split16 if split else lib.smirk_gap_linear
+    L.check(fn(L.ptr(feat), L.ptr(W_), L.ptr(b_), L.ptr(out), B, h * w, C, W_.shape[0], L.stream_ptr()))
     return out
 
 
@@ -205,7 +222,7 @@ class PoseEncoder(nn.Module):
             self.pose_cam_layers[-1].bias[3] = 7
 
     def forward(self, img):
-        pose_cam = _head(L.lib(), self.encoder(img), self.pose_cam_layers[0])
+        pose_cam = _head(L.lib(), self.encoder(img), self.pose_cam_layers[0], self.encoder._split)
         return {'pose_params': pose_cam[..., :3], 'cam': pose_cam[..., 3:]}
 
 
@@ -222,7 +239,7 @@ class ShapeEncoder(nn.Module):
             self.shape_layers[-1].bias.mul_(0)
 
     def forward(self, img):
-        return {'shape_params': _head(L.lib(), self.encoder(img), self.shape_layers[0])}
+        return {'shape_params': _head(L.lib(), self.encoder(img), self.shape_layers[0], self.encoder._split)}
 
 
 class ExpressionEncoder(nn.Module):
@@ -239,7 +256,7 @@ class ExpressionEncoder(nn.Module):
             self.expression_layers[-1].bias.mul_(0.1)
 
     def forward(self, img):
-        params = _head(L.lib(), self.encoder(img), self.expression_layers[0])
+        params = _head(L.lib(), self.encoder(img), self.expression_layers[0], self.encoder._split)
         L.check(L.lib().smirk_expression_clamps(L.ptr(params), params.shape[0], self.n_exp, L.stream_ptr()))
         n = self.n_exp
         return {'expression_params': params[..., :n], 'eyelid_params': params[..., n:n + 2],
