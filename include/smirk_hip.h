@@ -193,8 +193,8 @@ int smirk_stem_conv_s2(const float* img_nchw, const float* w /*[Cout][27] (ky,kx
 /* depthwise 3x3, stride 1 (pad 1) or 2 (TF-'same': pad 0 top/left, 1 bottom/right for even H), + scale/shift + ReLU. NHWC. */
 int smirk_dwconv3x3(const float* in, const float* w /*[9][C]*/, const float* scale, const float* shift, float* out,
                     int B, int H, int W, int C, int stride, int relu, void* stream);
-/* global average pool over HW then Linear: feat[B][HW][C] -> out[B][N] = mean_hw(feat) . Wt[N][C] + bias. */
-int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C, int N,
+/* global average pool over HW then Linear: feat[B][HW][C] -> out[B][N] = mean_hw(feat) . Wt[N][C] + bias; ws = [B][C] floats of scratch. */
+int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, float* ws, int B, int HW, int C, int N,
                      void* stream);
 /* split16 variants of the three encoder ops (activations in the split-fp16 format of smirk_conv_igemm_f16x3; weights / scale / shift fp32;
  * C and Cout multiples of 8): the stem writes split16, the depthwise stencil reads and writes it, the pooled head reads it. */
@@ -202,7 +202,8 @@ int smirk_stem_conv_s2_split16(const float* img_nchw, const float* w, const floa
                                int W, int Cout, void* stream);
 int smirk_dwconv3x3_split16(const void* in, const float* w /*[9][C]*/, const float* scale, const float* shift, void* out, int B, int H,
                             int W, int C, int stride, int relu, void* stream);
-int smirk_gap_linear_split16(const void* feat, const float* w, const float* bias, float* out, int B, int HW, int C, int N, void* stream);
+int smirk_gap_linear_split16(const void* feat, const float* w, const float* bias, float* out, float* ws, int B, int HW, int C, int N,
+                             void* stream);
 /* ExpressionEncoder output clamps (smirk_encoder.py:104-108), in place on params[B][n_exp+5]:
  * [n_exp, n_exp+2) clamp(0,1); [n_exp+2] relu; [n_exp+3, n_exp+5) clamp(-.2,.2). */
 int smirk_expression_clamps(float* params, int B, int n_exp, void* stream);

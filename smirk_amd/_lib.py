@@ -10,7 +10,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = C.c_void_p
 _i = C.c_int
@@ -73,10 +73,10 @@ _SIGS = {
     "smirk_conv1x1_sigmoid_nchw": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_stem_conv_s2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_dwconv3x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "smirk_gap_linear": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_gap_linear": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_stem_conv_s2_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_dwconv3x3_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "smirk_gap_linear_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_gap_linear_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_expression_clamps": (_i, [_p, _i, _i, _p]),
 }
 EXPORTS = tuple(_SIGS)

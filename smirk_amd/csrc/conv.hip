@@ -39,7 +39,7 @@ struct ConvArgs {
     const float *in0, *in1, *w, *scale, *shift, *residual;   // F16X3: in0/in1/w/residual/out are split-fp16 tensors viewed as dwords
     float* out;
     int M, N, K, Cin;
-    int ablate;    // diagnosis only (SMIRK_IGEMM_ABLATE): bit0 = no operand DMA after the first two chunks, bit1 = no MFMA/LDS reads
+    int ablate;    // reserved for ablation experiments (unused in the shipped kernels)
     int mfull;     // conv_igemm_mixed_kernel: number of full-height M tiles (the remaining rows use half-height tiles)
     int psh;       // GEMM rows enumerate each image in (2^psh x 2^psh)-pixel patches (tile-major): a BM-row tile is then a compact 2-D
                    // patch whose 3x3 halo is ~1.3x its area instead of 3 full image rows — the im2col re-reads stay in L1/L2

@@ -194,26 +194,29 @@ extern "C" int smirk_dwconv3x3(const float* in, const float* w, const float* sca
     return smirk_launch_status();
 }
 
-// global-average-pool + Linear head.  Grid (n-tile of 64 outputs, face): every workgroup re-pools its face's [HW][C] map into LDS
-// (a few hundred KB per face, L2-resident across the n-tiles) and then one wave per output neuron does a lane-strided dot product
-// with a shuffle reduction — 5 x more workgroups than one-per-face for the 300-wide shape head, which was latency-bound.
-__global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict__ feat, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ out, int HW,
-                                                         int C, int N, int split) {
+// global-average-pool + Linear head in two launches: (1) pooled[b][c] = mean over HW — one workgroup per (face, 256-channel slab), lanes over
+// channels so every load is coalesced; (2) out[b][n] = pooled[b] . W[n] + bias — grid (n-tile of 64, face), one wave per output neuron,
+// lane-strided dot product + shuffle reduction.  `ws` holds the pooled vectors ([B][C] floats).
+__global__ __launch_bounds__(256) void gap_pool_kernel(const float* __restrict__ feat, float* __restrict__ pooled, int HW, int C, int split) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* f = feat + (size_t)b * HW * C;
+    float s = 0.f;
+    if (split) {
+        const _Float16* h = (const _Float16*)f;
+        const int off = (c >> 3) * 16 + (c & 7);                        // halves: group base + hi lane; lo is 8 halves further
+        for (int p = 0; p < HW; ++p) s += enc_join(h[(size_t)p * C * 2 + off], h[(size_t)p * C * 2 + off + 8]);
+    } else {
+        for (int p = 0; p < HW; ++p) s += f[(size_t)p * C + c];
+    }
+    pooled[(size_t)b * C + c] = s / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict__ pooled_g, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int C, int N) {
     extern __shared__ float pooled[];
     const int b = blockIdx.y, n_lo = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* f = feat + (size_t)b * HW * C;
-    for (int c = tid; c < C; c += blockDim.x) {
-        float s = 0.f;
-        if (split) {
-            const _Float16* h = (const _Float16*)f;
-            const int off = (c >> 3) * 16 + (c & 7);                    // halves: group base + hi lane; lo is 8 halves further
-            for (int p = 0; p < HW; ++p) s += enc_join(h[(size_t)p * C * 2 + off], h[(size_t)p * C * 2 + off + 8]);
-        } else {
-            for (int p = 0; p < HW; ++p) s += f[(size_t)p * C + c];
-        }
-        pooled[c] = s / (float)HW;
-    }
+    for (int c = tid; c < C; c += blockDim.x) pooled[c] = pooled_g[(size_t)b * C + c];
     __syncthreads();
     const int n_hi = min(n_lo + 64, N);
     for (int n = n_lo + wave; n < n_hi; n += 4) {
@@ -226,19 +229,21 @@ __global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict
     }
 }
 
-static int gap_launch(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C, int N, void* stream, int split) {
-    if (!feat || !w || !out || B <= 0 || HW <= 0 || C <= 0 || N <= 0 || C > 8192 || (split && C % 8)) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gap_linear_kernel, dim3((N + 63) / 64, B), dim3(256), (size_t)C * 4, (hipStream_t)stream, feat, w, bias, out,
-                       HW, C, N, split);
+static int gap_launch(const float* feat, const float* w, const float* bias, float* out, float* ws, int B, int HW, int C, int N,
+                      void* stream, int split) {
+    if (!feat || !w || !out || !ws || B <= 0 || HW <= 0 || C <= 0 || N <= 0 || C > 8192 || (split && C % 8)) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gap_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feat, ws, HW, C, split);
+    hipLaunchKernelGGL(gap_linear_kernel, dim3((N + 63) / 64, B), dim3(256), (size_t)C * 4, (hipStream_t)stream, (const float*)ws, w, bias,
+                       out, C, N);
     return smirk_launch_status();
 }
-extern "C" int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, int B, int HW, int C,
+extern "C" int smirk_gap_linear(const float* feat, const float* w, const float* bias, float* out, float* ws, int B, int HW, int C,
                                 int N, void* stream) {
-    return gap_launch(feat, w, bias, out, B, HW, C, N, stream, 0);
+    return gap_launch(feat, w, bias, out, ws, B, HW, C, N, stream, 0);
 }
-extern "C" int smirk_gap_linear_split16(const void* feat, const float* w, const float* bias, float* out, int B, int HW, int C,
+extern "C" int smirk_gap_linear_split16(const void* feat, const float* w, const float* bias, float* out, float* ws, int B, int HW, int C,
                                         int N, void* stream) {
-    return gap_launch((const float*)feat, w, bias, out, B, HW, C, N, stream, 1);
+    return gap_launch((const float*)feat, w, bias, out, ws, B, HW, C, N, stream, 1);
 }
 
 __global__ void expression_clamps_kernel(float* __restrict__ p, int B, int n_exp) {

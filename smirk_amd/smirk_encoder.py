@@ -202,8 +202,9 @@ def _head(lib, feat, lin, split=False):
     W_ = lin.weight.detach().float().contiguous()
     b_ = lin.bias.detach().float().contiguous()
     out = torch.empty(B, W_.shape[0], device=feat.device)
+    ws = torch.empty(B, C, device=feat.device)
     fn = lib.smirk_gap_linear_split16 if split else lib.smirk_gap_linear
-    L.check(fn(L.ptr(feat), L.ptr(W_), L.ptr(b_), L.ptr(out), B, h * w, C, W_.shape[0], L.stream_ptr()))
+    L.check(fn(L.ptr(feat), L.ptr(W_), L.ptr(b_), L.ptr(out), L.ptr(ws), B, h * w, C, W_.shape[0], L.stream_ptr()))
     return out
 
 
