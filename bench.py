@@ -193,7 +193,7 @@ def main():
         L.TIMER = None
         dom = max(per, key=lambda k: per[k][1])
         fl, tm, n = per[dom]
-        split = dom.endswith("true>")
+        split = ",true," in dom or dom.endswith("true>")
         traffic = None                          # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes
         try:
             traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(dom)
@@ -202,7 +202,7 @@ def main():
         peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
         roof = {"bound": "mfma", "kernel": dom, "achieved": fl / tm / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": fl / tm / peak, "traffic": traffic, "launches_per_step": n,
-                "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc in separate passes (profiles/r01c_pmc_hbm.txt); "
+                "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc in separate passes (profiles/r01d_pmc_hbm.txt); "
                                 "includes Infinity-Cache hits; algorithmic operand bytes per launch = activations in + out + weights",
                 "mfma_issue_frac": (3.0 if split else 1.0) * fl / tm / peak,
                 "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per "

@@ -151,10 +151,12 @@ def timed(kernel, flops, fn):
     return r
 
 
-def igemm_kernel_name(n_gemm, split=False):
-    """Which conv_igemm_kernel instantiation smirk_conv_igemm_{f32,f16x3} dispatches for a GEMM N (mirrors conv.hip)."""
+def igemm_kernel_name(n_gemm, split=False, c0=32, c1=0, k=3):
+    """Which conv_igemm_kernel instantiation smirk_conv_igemm_{f32,f16x3} dispatches (mirrors conv.hip): tile by GEMM N, K-walk mode by
+    channel counts (1 = whole 32-channel chunks, 2 = 1x1 with a partial chunk, 0 = generic)."""
     t = "128,128,2,2" if n_gemm > 64 else "128,64,2,2" if n_gemm > 32 else "256,32,4,1"
-    return f"conv_igemm_kernel<{t},{'true' if split else 'false'}>"
+    kw = 1 if (c0 % 32 == 0 and c1 % 32 == 0) else (2 if k == 1 else 0)
+    return f"conv_igemm_kernel<{t},{'true' if split else 'false'},{kw}>"
 
 
 class Workspace:

@@ -144,7 +144,7 @@ class MobileNetV3Features(nn.Module):
         out = torch.empty(B, H, W, w.shape[0], device=x.device)
         P = L.ptr
         fn = lib.smirk_conv_igemm_f16x3 if self._split else lib.smirk_conv_igemm_f32
-        L.timed(L.igemm_kernel_name(w.shape[0], self._split), 2.0 * B * H * W * w.shape[0] * C, lambda: L.check(fn(
+        L.timed(L.igemm_kernel_name(w.shape[0], self._split, C, 0, 1), 2.0 * B * H * W * w.shape[0] * C, lambda: L.check(fn(
             d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st)))
         return out
 

@@ -150,7 +150,7 @@ class SmirkGenerator(nn.Module):
         n_gemm = 4 * cout if convt else cout
         flops = 2.0 * B * H * W * n_gemm * (k * k * (d.C0 + d.C1))
         fn = lib.smirk_conv_igemm_f16x3 if self._split else lib.smirk_conv_igemm_f32
-        L.timed(L.igemm_kernel_name(n_gemm, self._split), flops, lambda: L.check(fn(
+        L.timed(L.igemm_kernel_name(n_gemm, self._split, d.C0, d.C1, k), flops, lambda: L.check(fn(
             d, P(x0), P(x1, allow_none=True), P(w), P(scale, allow_none=True), P(shift, allow_none=True),
             P(residual, allow_none=True), P(out), st)))
         return out
