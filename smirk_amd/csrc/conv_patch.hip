@@ -12,6 +12,8 @@
 // A concatenated input (decoder: up ++ skip) is two source tensors, one chunk sequence each.
 //
 // Bound: HBM (activation read 1.27x + write 1x) once the DMA is hidden; MFMA work is ~40 % of that time.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -145,37 +147,45 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
         }
         const float* A = St + st * PSTAGE;
         const float* Wc = Wl + cc * 9 * COUT * 32;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int pc = 2 * (2 * s + hb);
-                half8 ah[2], al[2], bh[TN], bl[TN];
+        // 18 (tap, 16-k step) stages, software-pipelined in registers: the LDS reads of stage t+1 are issued before the MFMAs of stage t
+        {
+            half8 ah[2][2], al[2][2], bh[2][TN], bl[2][TN];
+            auto fetch = [&](int t, int set) {
+                const int tap = t >> 1, sstep = t & 1, ky = tap / 3, kx = tap % 3;
+                const int pc = 2 * (2 * sstep + hb);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int pix = (4 * wave + 2 * i + ry + ky) * PH + rx + kx;
-                    ah[i] = *(const half8*)(A + lds_piece_p(pix, pc));
-                    al[i] = *(const half8*)(A + lds_piece_p(pix, pc + 1));
+                    ah[set][i] = *(const half8*)(A + lds_piece_p(pix, pc));
+                    al[set][i] = *(const half8*)(A + lds_piece_p(pix, pc + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = tap * COUT + j * 32 + fr;
-                    bh[j] = *(const half8*)(Wc + lds_piece_p(row, pc));
-                    bl[j] = *(const half8*)(Wc + lds_piece_p(row, pc + 1));
+                    bh[set][j] = *(const half8*)(Wc + lds_piece_p(row, pc));
+                    bl[set][j] = *(const half8*)(Wc + lds_piece_p(row, pc + 1));
                 }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int t = 0; t < 18; ++t) {
+                const int cur = t & 1;
+                if (t + 1 < 18) fetch(t + 1, cur ^ 1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur][j], acc0[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur][j], acc1[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur][j], acc1[i][j], 0, 0, 0);
+                // pin the software pipeline: [LDS reads of stage t+1][MFMAs of stage t] (hipcc otherwise re-serialises read-wait-MFMA)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);
             }
         }
         if (cc == a.nchunk - 1) {
@@ -254,15 +264,196 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
     }
 }
 
+// Streamed-weights variant for Cout = 64 layers whose weight tensor does not fit in LDS next to the input stages (64->64, 128->64 at 112x112).
+// The 64 output channels are processed as two halves of 32 (one N-tile each): a pipeline ITEM is (patch, 32-channel chunk, half); the
+// half-chunk weights [9 taps][32][32 dwords] = 36 KiB are double-buffered like the input halo stages, so 2 x 36 + 2 x 41 = 154 KiB of the
+// CU's 160 KiB LDS are in use.  While item i computes, the DMA for item i+1 (its weights, and its input stage when it starts a new chunk)
+// is in flight.  Both halves' accumulators live in registers across the chunks of a patch; one epilogue per patch writes all 64 channels.
+#define WSTAGE (9 * 32 * 32)     // dwords per weight stage (one half-chunk)
+__global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int COUT = 64, EPI_LD = COUT + 4;
+    static_assert(4 * 32 * EPI_LD <= PSTAGE, "transpose buffers must fit in one input stage");
+    float* Wst = smem;                                           // 2 weight stages
+    float* St = smem + 2 * WSTAGE;                               // 2 input stages
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, hb = lane >> 5;
+    const int Cin = a.C0 + a.C1, K = 9 * Cin;
+
+    constexpr int NQ = (PPIX + 31) / 32;
+    int hp_y[NQ], hp_x[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pix = (q * 4 + wave) * 8 + (lane >> 3);
+        hp_y[q] = pix < PPIX ? pix / PH : -100000;
+        hp_x[q] = pix - (pix / PH) * PH;
+    }
+    const int tiles_x = a.W / PT, tiles_per_img = (a.H / PT) * tiles_x;
+    auto patch_origin = [&](int p, int& b, int& oy0, int& ox0) {
+        b = p / tiles_per_img;
+        const int t = p - b * tiles_per_img;
+        oy0 = (t / tiles_x) * PT;
+        ox0 = (t - (t / tiles_x) * tiles_x) * PT;
+    };
+    auto issue_input = [&](int p, int cc, int st) {
+        int b, oy0, ox0;
+        patch_origin(p, b, oy0, ox0);
+        const int c0 = cc * 32;
+        const bool s1 = c0 >= a.C0;
+        const float* src = s1 ? a.in1 : a.in0;
+        const int cs = s1 ? a.C1 : a.C0, cb = s1 ? c0 - a.C0 : c0;
+        float* dst = St + st * PSTAGE;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pixbase = (q * 4 + wave) * 8;
+            if (pixbase < PPIX) {
+                const int pix = pixbase + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
+                const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                const float* g = ok ? src + ((size_t)(b * a.H + iy) * a.W + ix) * cs + cb + piece * 4 : g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + pixbase * 32), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_weights = [&](int cc, int h, int st) {
+        float* dst = Wst + st * WSTAGE;
+        for (int r0 = wave * 8; r0 < 9 * 32; r0 += 32) {         // 288 rows: (tap, n), 8 rows per wave instruction
+            const int row = r0 + (lane >> 3), piece = (lane & 7) ^ ((row >> 1) & 7);
+            const int tap = row >> 5, n = h * 32 + (row & 31);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.w + (size_t)n * K + tap * Cin + cc * 32 + piece * 4), (lptr_t)(dst + r0 * 32), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc0[2][2], acc1[2][2];                               // [half][M-tile]
+    const int ry = fr >> 4, rx = fr & 15;
+    // 18 (tap, 16-k step) stages, software-pipelined in registers: the LDS reads of stage t+1 are issued before the MFMAs of stage t
+    auto run = [&](const float* A, const float* Wc, f32x16 (&c0)[2], f32x16 (&c1)[2]) {
+        half8 ah[2][2], al[2][2], bh[2], bl[2];
+        auto fetch = [&](int t, int set) {
+            const int tap = t >> 1, sstep = t & 1, ky = tap / 3, kx = tap % 3;
+            const int pc = 2 * (2 * sstep + hb);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pix = (4 * wave + 2 * i + ry + ky) * PH + rx + kx;
+                ah[set][i] = *(const half8*)(A + lds_piece_p(pix, pc));
+                al[set][i] = *(const half8*)(A + lds_piece_p(pix, pc + 1));
+            }
+            const int row = tap * 32 + fr;
+            bh[set] = *(const half8*)(Wc + lds_piece_p(row, pc));
+            bl[set] = *(const half8*)(Wc + lds_piece_p(row, pc + 1));
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < 18) fetch(t + 1, cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], c0[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], c1[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], c1[i], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+    };
+    auto stage_ready = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // pipeline over (patch, chunk); each chunk is two straight-line half items (h = 0, 1) so the accumulator sets are compile-time fixed.
+    // Weight stage h holds half h of the current chunk; input stage (chunk_no & 1) holds the current chunk's halo patch.
+    int chunk_no = 0;
+    int p = blockIdx.x, cc = 0;
+    if (p < a.npatch) { issue_input(p, 0, 0); issue_weights(0, 0, 0); }
+    while (p < a.npatch) {
+        int np = p, ncc = cc + 1;
+        if (ncc == a.nchunk) { ncc = 0; np = p + gridDim.x; }
+        const float* A = St + (chunk_no & 1) * PSTAGE;
+        // ---- half 0: its weights (stage 0) and the chunk's input have landed; prefetch half 1's weights into stage 1 ----------------
+        stage_ready();
+        issue_weights(cc, 1, 1);
+        if (cc == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[0][i][r] = 0.f; acc1[0][i][r] = 0.f; acc0[1][i][r] = 0.f; acc1[1][i][r] = 0.f; }
+        }
+        run(A, Wst, acc0[0], acc1[0]);
+        // ---- half 1: prefetch the NEXT chunk (weights half 0 into stage 0, input into the other input stage) ---------------------------
+        stage_ready();
+        if (np < a.npatch) { issue_weights(ncc, 0, 0); issue_input(np, ncc, (chunk_no + 1) & 1); }
+        run(A, Wst + WSTAGE, acc0[1], acc1[1]);
+        if (cc == a.nchunk - 1) {
+            int b, oy0, ox0;
+            patch_origin(p, b, oy0, ox0);
+            __syncthreads();                                     // the current input stage is dead: per-wave transpose buffers
+            float* ebuf = St + (chunk_no & 1) * PSTAGE + wave * 32 * EPI_LD;
+            constexpr int GPR = COUT / 8, ITEMS = 32 * GPR / 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc0[j][i][r] + acc1[j][i][r] * (1.0f / 2048.0f);
+                __syncthreads();
+#pragma unroll
+                for (int e0 = 0; e0 < ITEMS; ++e0) {
+                    const int e = e0 * 64 + lane, row = e / GPR, g = e % GPR;
+                    const int oy = oy0 + 4 * wave + 2 * i + (row >> 4), ox = ox0 + (row & 15);
+                    float v[8];
+                    *(f32x4*)v = *(const f32x4*)(ebuf + row * EPI_LD + g * 8);
+                    *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * EPI_LD + g * 8 + 4);
+                    if (a.scale) {
+                        const f32x4 s0 = *(const f32x4*)(a.scale + g * 8), s1 = *(const f32x4*)(a.scale + g * 8 + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+                    }
+                    if (a.shift) {
+                        const f32x4 s0 = *(const f32x4*)(a.shift + g * 8), s1 = *(const f32x4*)(a.shift + g * 8 + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
+                    }
+                    if (a.act == SMIRK_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    half8 hi, lo;
+                    split8p(v, hi, lo);
+                    float* o = a.out + (((size_t)b * a.H + oy) * a.W + ox) * COUT + g * 8;
+                    *(half8*)o = hi;
+                    *(half8*)(o + 4) = lo;
+                }
+                __syncthreads();
+            }
+        }
+        ++chunk_no;
+        p = np; cc = ncc;
+    }
+}
+
 // Can this layer run on the patch kernel?  (3x3, stride 1, zero pad 1, same size, H,W % 16 == 0, Cout 32/64, weights resident)
-static bool patch_eligible(const SmirkConvDesc* d, bool has_residual) {
+static bool patch_common(const SmirkConvDesc* d, bool has_residual) {
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->pad_mode != SMIRK_PAD_ZERO) return false;
     if (d->out_mode != SMIRK_OUT_NHWC || d->Ho != d->H || d->Wo != d->W || d->H % PT || d->W % PT || has_residual) return false;
     if (d->Cout != 32 && d->Cout != 64) return false;
     if (d->C1 > 0 && d->C0 % 32) return false;
+    return d->H >= 64;
+}
+static bool patch_resident(const SmirkConvDesc* d) {             // whole weight tensor fits next to two input stages
     const int nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
-    const size_t lds = ((size_t)nchunk * 9 * d->Cout * 32 + 2 * PSTAGE) * 4;
-    return lds <= 160 * 1024 && d->H >= 64;
+    return ((size_t)nchunk * 9 * d->Cout * 32 + 2 * PSTAGE) * 4 <= 160 * 1024;
+}
+static bool patch_streamed(const SmirkConvDesc* d) {             // Cout = 64, whole 32-channel chunks: weights streamed per half-chunk
+    // measured (B=128, 112x112): 128->64 0.90 ms vs 1.02 ms on the implicit-GEMM kernel, 64->64 0.53 vs 0.50 ms => only for >= 4 chunks
+    return d->Cout == 64 && d->C0 % 32 == 0 && d->C1 % 32 == 0 && (d->C0 + d->C1) >= 128 && getenv("SMIRK_DISABLE_PATCH_STREAM") == nullptr;
+}
+static bool patch_eligible(const SmirkConvDesc* d, bool has_residual) {
+    return patch_common(d, has_residual) && (patch_resident(d) || patch_streamed(d));
 }
 
 int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
@@ -274,6 +465,13 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
     a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
     a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
     a.npatch = d->B * (d->H / PT) * (d->W / PT);
+    if (!patch_resident(d)) {
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute((const void*)conv3x3_patch_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+        const size_t lds2 = (size_t)(2 * WSTAGE + 2 * PSTAGE) * 4;
+        hipLaunchKernelGGL(conv3x3_patch_stream_kernel, dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), lds2, st, a);
+        return smirk_launch_status();
+    }
     const size_t wbytes = (size_t)a.nchunk * 9 * d->Cout * 32 * 4;
     const bool one_stage = (wbytes + (size_t)PSTAGE * 4) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
     const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4;

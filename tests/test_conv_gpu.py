@@ -47,7 +47,8 @@ def _run(B, H, C0, C1, Cout, k=3, reflect=False, seed=0):
 
 # (B, H, C0, C1, Cout): patch-kernel shapes (H >= 64, Cout 32/64, weights resident) incl. >2 patches per workgroup, 2 sources,
 # the 8-channel first layer; and implicit-GEMM shapes (small images, wide layers, reflect padding, ragged M)
-CASES = [(2, 224, 32, 32, 32), (3, 224, 8, 0, 32), (2, 224, 32, 0, 32), (5, 112, 32, 0, 64), (2, 64, 32, 32, 32),
+CASES = [(2, 112, 128, 0, 64), (3, 112, 64, 64, 64), (2, 64, 128, 0, 64),       # streamed-weights patch kernel (Cout 64, weights > LDS)
+         (2, 224, 32, 32, 32), (3, 224, 8, 0, 32), (2, 224, 32, 0, 32), (5, 112, 32, 0, 64), (2, 64, 32, 32, 32),
          (2, 32, 32, 0, 32), (3, 28, 64, 64, 128), (5, 14, 128, 0, 256), (1, 56, 64, 0, 64)]
 
 
