@@ -183,9 +183,6 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur][j], acc1[i][j], 0, 0, 0);
-                // pin the software pipeline: [LDS reads of stage t+1][MFMAs of stage t] (hipcc otherwise re-serialises read-wait-MFMA)
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * TN, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);
             }
         }
         if (cc == a.nchunk - 1) {
