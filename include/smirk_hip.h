@@ -74,14 +74,31 @@ size_t smirk_flame_workspace_bytes(const SmirkFlameModel* m /*host struct*/, int
 /* Inputs [B,*]; `neck`, `eye`, `eyelid` may be NULL (=> zeros / no eyelid term, FLAME.py:267-271,284).
  * ns_in / ne_in: number of shape / expression coefficients actually supplied (right-padded with zeros, FLAME.py:244-248).
  * Outputs: verts[B][V][3], lmk_fan[B][n_dyn+n_static][3], lmk_fan3d[B][n_full][3], lmk_mp[B][n_mp][3];
- * lut_idx_out (nullable) [B] int32 = the dynamic-contour LUT row chosen per face (for parity tests).
+ * lut_idx_out (nullable) [B] int32 = the dynamic-contour LUT row chosen per face (parity tests; needed by the backward pass).
+ * v_posed_out (nullable) [B][V][3] = vertices before skinning (lbs.py:202), saved for smirk_flame_backward.
  * `m` is a HOST struct whose members are device pointers. */
 int smirk_flame_forward(const SmirkFlameModel* m, int B,
                         const float* shape, int ns_in, const float* exp, int ne_in,
                         const float* global_pose /*[B,3]*/, const float* neck /*[B,3]*/, const float* jaw /*[B,3]*/,
                         const float* eye /*[B,6]*/, const float* eyelid /*[B,2]*/,
                         float* verts, float* lmk_fan, float* lmk_fan3d, float* lmk_mp, int32_t* lut_idx_out,
-                        void* ws, size_t ws_bytes, void* stream);
+                        float* v_posed_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of smirk_flame_forward — what autograd computes through FLAME.forward in the reference's training step
+ * (smirk_trainer.py:94-104 flame.forward on encoder outputs that require grad; lbs.py:139-225 is differentiated end to end).
+ * Given dL/dvertices and dL/dlandmarks_* (each nullable = zero), writes dL/dshape[B][ns_in], dL/dexp[B][ne_in], dL/dglobal_pose[B][3],
+ * dL/djaw[B][3], and when the pointers are non-NULL dL/dneck[B][3], dL/deye[B][6], dL/deyelid[B][2] (d_eyelid required iff eyelid given).
+ * The dynamic-contour LUT row is piecewise constant in the pose (FLAME.py:137-153 rounds to an integer), so it carries no gradient.
+ * dirs_t[KP][3*VP]: the blendshape basis of SmirkFlameModel.dirs transposed to coefficient-major (a constant the host builds once).
+ * v_posed / lut_idx: the v_posed_out / lut_idx_out of the forward call on the same inputs. */
+size_t smirk_flame_backward_workspace_bytes(const SmirkFlameModel* m /*host struct*/, int B);
+int smirk_flame_backward(const SmirkFlameModel* m, const float* dirs_t, int B,
+                         const float* shape, int ns_in, const float* exp, int ne_in,
+                         const float* global_pose, const float* neck, const float* jaw, const float* eye, const float* eyelid,
+                         const float* v_posed, const int32_t* lut_idx,
+                         const float* g_verts, const float* g_lmk_fan, const float* g_lmk_fan3d, const float* g_lmk_mp,
+                         float* d_shape, float* d_exp, float* d_global_pose, float* d_neck, float* d_jaw, float* d_eye, float* d_eyelid,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* Barycentric landmark gather on its own — replaces vertices2landmarks (lbs.py:101-137) as used by
  * utils/masking.py:170 with per-face index/bary tensors.  faces_idx[B][L] int32, bary[B][L][3] -> out[B][L][3]. */

@@ -3,10 +3,11 @@
 Regenerates tests/golden/*.npz by running the REAL reference classes (imported from /root/reference through
 oracle/sandbox.py) on seeded synthetic inputs.  Runs only in the build container; the fixtures travel to the GPU box.
 
-    python -m oracle.make_golden            # writes tests/golden/{assets_bundle,flame,render,generator,encoder}_golden.npz
+    python -m oracle.make_golden            # writes tests/golden/{assets_bundle,flame,flame_grad,render,generator,encoder,masking}_golden.npz
 
 What each fixture pins
   flame_golden      reference FLAME.forward (FLAME.py:232-315) outputs, B=4                      -> fully pinned
+  flame_grad_golden autograd through the reference FLAME.forward of a fixed random linear loss, B=3 -> fully pinned
   generator_golden  reference SmirkGenerator(6,3,32,5).eval() (smirk_generator.py:51-86), B=1    -> fully pinned
   render_golden     reference Renderer.forward (renderer.py:100-207) on top of oracle/raster_ref.c -> glue pinned,
                     rasteriser itself PARITY UNPINNED (pytorch3d not on disk)
@@ -105,6 +106,16 @@ def main():
                             bary=bary.numpy(), npoints=npts.numpy(), masked_sub2=masked.numpy()[:, :, ::2, ::2],
                             masked_sum=np.float64(masked.double().sum()), transfer_nonzero=np.int64((tp != 0).sum()),
                             transfer_sum=np.float64(tp.double().sum()), img_seed=41)
+    # ---- FLAME gradients: autograd through the REAL reference FLAME, B=3 --------------------------
+    from .flame_torch_ref import scalar_loss
+    with S.reference(d) as ref:
+        fl = ref.FLAME()
+        p = A.synth_flame_params(3, seed=17)
+        tp = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in p.items()}
+        loss, _ = scalar_loss(fl.forward(tp), seed=3)
+        loss.backward()
+        np.savez_compressed(os.path.join(GOLD, "flame_grad_golden.npz"), seed=17, loss_seed=3, loss=np.float64(loss.item()),
+                            **{"in_" + k: v for k, v in p.items()}, **{"d_" + k: v.grad.numpy() for k, v in tp.items()})
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
 

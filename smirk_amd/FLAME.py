@@ -107,6 +107,7 @@ class FLAME(nn.Module):
         self._ws = L.Workspace()
         self._model_struct = None
         self._model_key = None
+        self._k_dirs_t = None
 
     # ------------------------------------------------------------------------------------------------------------
     def _struct(self):
@@ -152,22 +153,83 @@ class FLAME(nn.Module):
         eye = L.as_f32c(self.eye_pose.expand(B, -1) if eye is None else eye)
         neck = L.as_f32c(self.neck_pose.expand(B, -1) if neck is None else neck)
         eyelid = None if eyelid is None else L.as_f32c(eyelid)
+        needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                     for t in (shape, exp, pose, neck, jaw, eye, eyelid))
+        if needs_grad:                                     # training step 1 (smirk_trainer.py:94-104): differentiable w.r.t. the parameters
+            has_eyelid = eyelid is not None
+            verts, fan, fan3d, mp = _FlameFunction.apply(self, has_eyelid, shape, exp, pose, neck, jaw, eye,
+                                                         eyelid if has_eyelid else shape.new_zeros(B, 2))
+            lut = None
+        else:
+            verts, fan, fan3d, mp, lut, _ = self._launch(shape, exp, pose, neck, jaw, eye, eyelid, _return_lut, False)
+        out = {'vertices': verts, 'landmarks_fan': fan, 'landmarks_fan_3d': fan3d, 'landmarks_mp': mp}
+        if _return_lut:
+            out['_lut_idx'] = lut
+        return out
+
+    def _launch(self, shape, exp, pose, neck, jaw, eye, eyelid, want_lut, want_vposed):
         d = self._dims
         m = self._struct()
         lib = L.lib()
+        B, dev = shape.shape[0], shape.device
         verts = torch.empty(B, d['V'], 3, device=dev)
         fan = torch.empty(B, d['n_dyn'] + d['n_static'], 3, device=dev)
         fan3d = torch.empty(B, d['n_full'], 3, device=dev)
         mp = torch.empty(B, d['n_mp'], 3, device=dev)
-        lut = torch.empty(B, dtype=torch.int32, device=dev) if _return_lut else None
+        lut = torch.empty(B, dtype=torch.int32, device=dev) if want_lut else None
+        vposed = torch.empty(B, d['V'], 3, device=dev) if want_vposed else None
         nws = lib.smirk_flame_workspace_bytes(m, B)
         ws = self._ws.get(nws, dev)
         P = L.ptr
         L.check(lib.smirk_flame_forward(m, B, P(shape), shape.shape[1], P(exp), exp.shape[1], P(pose), P(neck, allow_none=True),
                                         P(jaw), P(eye, allow_none=True), P(eyelid, allow_none=True), P(verts), P(fan),
-                                        P(fan3d), P(mp), P(lut, torch.int32, allow_none=True), P(ws, torch.uint8), nws,
-                                        L.stream_ptr()))
-        out = {'vertices': verts, 'landmarks_fan': fan, 'landmarks_fan_3d': fan3d, 'landmarks_mp': mp}
-        if _return_lut:
-            out['_lut_idx'] = lut
-        return out
+                                        P(fan3d), P(mp), P(lut, torch.int32, allow_none=True), P(vposed, allow_none=True),
+                                        P(ws, torch.uint8), nws, L.stream_ptr()))
+        return verts, fan, fan3d, mp, lut, vposed
+
+    def _dirs_t(self):
+        """[KP][3*VP] coefficient-major copy of the blendshape basis for the backward GEMM; built on first use (25 MB)."""
+        if self._k_dirs_t is None or self._k_dirs_t.device != self._k_dirs.device:
+            d = self._dims
+            self._k_dirs_t = self._k_dirs.reshape(3 * d['VP'], d['KP']).t().contiguous()
+        return self._k_dirs_t
+
+    def _launch_backward(self, shape, exp, pose, neck, jaw, eye, eyelid, vposed, lut, grads):
+        d = self._dims
+        m = self._struct()
+        lib = L.lib()
+        B, dev = shape.shape[0], shape.device
+        z = lambda *s: torch.empty(*s, device=dev)
+        d_shape, d_exp, d_pose, d_neck, d_jaw, d_eye = z(B, shape.shape[1]), z(B, exp.shape[1]), z(B, 3), z(B, 3), z(B, 3), z(B, 6)
+        d_eyelid = z(B, 2) if eyelid is not None else None
+        g = [None if t is None else L.as_f32c(t) for t in grads]
+        nws = lib.smirk_flame_backward_workspace_bytes(m, B)
+        ws = self._ws.get(nws, dev)
+        P = L.ptr
+        N = lambda t: P(t, allow_none=True)
+        L.check(lib.smirk_flame_backward(m, P(self._dirs_t()), B, P(shape), shape.shape[1], P(exp), exp.shape[1], P(pose), N(neck), P(jaw),
+                                         N(eye), N(eyelid), P(vposed), P(lut, torch.int32), N(g[0]), N(g[1]), N(g[2]), N(g[3]),
+                                         P(d_shape), P(d_exp), P(d_pose), P(d_neck), P(d_jaw), P(d_eye), N(d_eyelid),
+                                         P(ws, torch.uint8), nws, L.stream_ptr()))
+        return d_shape, d_exp, d_pose, d_neck, d_jaw, d_eye, d_eyelid
+
+
+class _FlameFunction(torch.autograd.Function):
+    """autograd bridge: forward = smirk_flame_forward (saving v_posed + the LUT row), backward = smirk_flame_backward."""
+
+    @staticmethod
+    def forward(ctx, module, has_eyelid, shape, exp, pose, neck, jaw, eye, eyelid):
+        eyl = eyelid if has_eyelid else None
+        verts, fan, fan3d, mp, lut, vposed = module._launch(shape, exp, pose, neck, jaw, eye, eyl, True, True)
+        ctx.module, ctx.has_eyelid = module, has_eyelid
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(shape, exp, pose, neck, jaw, eye, eyelid, vposed, lut)
+        return verts, fan, fan3d, mp
+
+    @staticmethod
+    def backward(ctx, g_verts, g_fan, g_fan3d, g_mp):
+        shape, exp, pose, neck, jaw, eye, eyelid, vposed, lut = ctx.saved_tensors
+        eyl = eyelid if ctx.has_eyelid else None
+        d = ctx.module._launch_backward(shape, exp, pose, neck, jaw, eye, eyl, vposed, lut, (g_verts, g_fan, g_fan3d, g_mp))
+        d_shape, d_exp, d_pose, d_neck, d_jaw, d_eye, d_eyelid = d
+        return None, None, d_shape, d_exp, d_pose, d_neck, d_jaw, d_eye, d_eyelid

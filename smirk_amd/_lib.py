@@ -10,7 +10,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = C.c_void_p
 _i = C.c_int
@@ -44,7 +44,10 @@ _SIGS = {
     "smirk_abi_version": (_i, []),
     "smirk_flame_workspace_bytes": (_sz, [C.POINTER(SmirkFlameModel), _i]),
     "smirk_flame_forward": (_i, [C.POINTER(SmirkFlameModel), _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                 _p, _sz, _p]),
+                                 _p, _p, _sz, _p]),
+    "smirk_flame_backward_workspace_bytes": (_sz, [C.POINTER(SmirkFlameModel), _i]),
+    "smirk_flame_backward": (_i, [C.POINTER(SmirkFlameModel), _p, _i, _p, _i, _p, _i] + [_p] * 5 + [_p, _p] + [_p] * 4 + [_p] * 7 +
+                             [_p, _sz, _p]),
     "smirk_vertices2landmarks": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p]),
     "smirk_render_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
     "smirk_render_forward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

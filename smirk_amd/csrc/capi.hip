@@ -12,4 +12,4 @@ extern "C" const char* smirk_strerror(int code) {
     }
 }
 
-extern "C" int smirk_abi_version(void) { return 2; }
+extern "C" int smirk_abi_version(void) { return 3; }

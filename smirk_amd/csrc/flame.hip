@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64) void flame_prologue(FlameDev m, int B, const fl
 
 __global__ __launch_bounds__(256) void flame_blend_skin(FlameDev m, int B, const float* __restrict__ coef,
                                                         const float* __restrict__ amat,
-                                                        const float* __restrict__ eyelid, float* __restrict__ verts) {
+                                                        const float* __restrict__ eyelid, float* __restrict__ verts,
+                                                        float* __restrict__ vposed) {
     __shared__ __attribute__((aligned(16))) float smem[(FL_BM + 3 * FL_BV) * FL_LDS_STRIDE];
     float* As = smem;
     float* Bs = smem + FL_BM * FL_LDS_STRIDE;
@@ -221,6 +222,10 @@ __global__ __launch_bounds__(256) void flame_blend_skin(FlameDev m, int B, const
         const int b = b0 + fb;
         if (b >= B) continue;
         const float x = acc[0][r] + vt[0], y = acc[1][r] + vt[1], z = acc[2][r] + vt[2];
+        if (vposed) {                                             // saved for the backward pass (lbs.py:202 v_posed)
+            float* vp = vposed + ((size_t)b * m.V + v) * 3;
+            vp[0] = x; vp[1] = y; vp[2] = z;
+        }
         const float* A = smem + fb * 60;
         float T[12];
 #pragma unroll
@@ -284,6 +289,267 @@ __global__ __launch_bounds__(256) void v2l_kernel(const float* __restrict__ vert
     lmk_one(verts + (size_t)b * V * 3, faces, fidx[i], bary + i * 3, out + i * 3);
 }
 
+// ====================================================================================================================================
+// Backward pass: gradients of a scalar loss w.r.t. shape / expression / pose / jaw / eyelid given the gradients of the
+// four outputs — what autograd does through FLAME.forward in the reference's training step 1 (smirk_trainer.py:37-48,94-104,362).
+//   flame_bwd_gather   G = dL/dvertices + the landmark gradients scattered back through their barycentric gathers
+//   flame_bwd_skin     one workgroup per face: dL/dv_posed = R_v^T g_v (planar, feeds the GEMM), and the reductions over all vertices of
+//                      dL/dA_j (5 joints x 3x4) and dL/deyelid
+//   GEMM               dL/dcoef[B][KP] = dL/dv_posed[B][3*VP] x dirs_t[KP][3*VP]^T   (fp32 MFMA implicit-GEMM kernel, 1x1 mode)
+//   flame_bwd_chain    one wave per face: kinematic chain + Rodrigues backward -> dL/dpose; joints -> betas via jdirs^T; split into outputs
+// ====================================================================================================================================
+__global__ __launch_bounds__(256) void flame_bwd_gather(FlameDev m, int B, const float* __restrict__ g_verts,
+                                                        const float* __restrict__ g_fan, const float* __restrict__ g_fan3d,
+                                                        const float* __restrict__ g_mp, const int32_t* __restrict__ lut,
+                                                        float* __restrict__ G) {
+    const int b = blockIdx.x;
+    float* Gb = G + (size_t)b * m.V * 3;
+    for (int i = threadIdx.x; i < m.V * 3; i += blockDim.x) Gb[i] = g_verts ? g_verts[(size_t)b * m.V * 3 + i] : 0.f;
+    __syncthreads();
+    const int nfan = m.n_dyn + m.n_static, total = nfan + m.n_full + m.n_mp;
+    const int row = lut[b];
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int f; const float* bc; const float* g;
+        if (i < m.n_dyn) { f = m.dyn_faces[row * m.n_dyn + i]; bc = m.dyn_bary + ((size_t)row * m.n_dyn + i) * 3; g = g_fan ? g_fan + ((size_t)b * nfan + i) * 3 : nullptr; }
+        else if (i < nfan) { const int s = i - m.n_dyn; f = m.static_faces[s]; bc = m.static_bary + s * 3; g = g_fan ? g_fan + ((size_t)b * nfan + i) * 3 : nullptr; }
+        else if (i < nfan + m.n_full) { const int s = i - nfan; f = m.full_faces[s]; bc = m.full_bary + s * 3; g = g_fan3d ? g_fan3d + ((size_t)b * m.n_full + s) * 3 : nullptr; }
+        else { const int s = i - nfan - m.n_full; f = m.mp_faces[s]; bc = m.mp_bary + s * 3; g = g_mp ? g_mp + ((size_t)b * m.n_mp + s) * 3 : nullptr; }
+        if (!g) continue;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int vi = m.faces[f * 3 + k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&Gb[vi * 3 + c], bc[k] * g[c]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void flame_bwd_skin(FlameDev m, int B, const float* __restrict__ G, const float* __restrict__ vposed,
+                                                      const float* __restrict__ amat, const float* __restrict__ eyelid_in,
+                                                      float* __restrict__ gvp /*[B][3][VP]*/, float* __restrict__ dA /*[B][60]*/,
+                                                      float* __restrict__ deyelid /*[B][2]*/) {
+    __shared__ float sA[60];
+    __shared__ float red[4][62];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 60) sA[tid] = amat[(size_t)b * 60 + tid];
+    __syncthreads();
+    float acc[62];
+#pragma unroll
+    for (int i = 0; i < 62; ++i) acc[i] = 0.f;
+    for (int v = tid; v < m.VP; v += 256) {
+        float gx = 0.f, gy = 0.f, gz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+        if (v < m.V) {
+            const float* g = G + ((size_t)b * m.V + v) * 3;
+            const float* vp = vposed + ((size_t)b * m.V + v) * 3;
+            gx = g[0]; gy = g[1]; gz = g[2];
+            const float px = vp[0], py = vp[1], pz = vp[2];
+            float w[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) w[j] = m.lbs_weights[(size_t)v * 5 + j];
+            float R[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) s = fmaf(w[j], sA[j * 12 + r * 4 + c], s);
+                    R[r * 3 + c] = s;
+                }
+            ox = R[0] * gx + R[3] * gy + R[6] * gz;                 // R^T g
+            oy = R[1] * gx + R[4] * gy + R[7] * gz;
+            oz = R[2] * gx + R[5] * gy + R[8] * gz;
+            const float ph[4] = {px, py, pz, 1.0f}, gg[3] = {gx, gy, gz};
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[j * 12 + r * 4 + c] = fmaf(w[j] * gg[r], ph[c], acc[j * 12 + r * 4 + c]);
+            if (eyelid_in) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    acc[60] = fmaf(gg[c], m.l_eyelid[(size_t)v * 3 + c], acc[60]);
+                    acc[61] = fmaf(gg[c], m.r_eyelid[(size_t)v * 3 + c], acc[61]);
+                }
+            }
+        }
+        float* o = gvp + (size_t)b * 3 * m.VP;
+        o[v] = ox; o[m.VP + v] = oy; o[2 * m.VP + v] = oz;
+    }
+#pragma unroll
+    for (int i = 0; i < 62; ++i) {
+        float s = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (tid < 62) {
+        const float s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (tid < 60) dA[(size_t)b * 60 + tid] = s; else deyelid[(size_t)b * 2 + (tid - 60)] = s;
+    }
+}
+
+// dL/dr of R = rodrigues(r) given G = dL/dR   (forward: lbs.py:274-305)
+__device__ inline void rodrigues_bwd(const float* r, const float* G, float* dr) {
+    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
+    const float th = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float u[3] = {r[0] / th, r[1] / th, r[2] / th};
+    const float c = cosf(th), s = sinf(th), omc = 1.0f - c;
+    const float K[9] = {0.f, -u[2], u[1], u[2], 0.f, -u[0], -u[1], u[0], 0.f};
+    float KK[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) KK[i * 3 + j] = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+    float gk = 0.f, gkk = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { gk += G[i] * K[i]; gkk += G[i] * KK[i]; }
+    float dth = gk * c + gkk * s;                               // via sin(th) K and (1 - cos th) K^2
+    float dK[9];                                                // s G + (1-c) (G K^T + K^T G)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float gkt = 0.f, ktg = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gkt += G[i * 3 + k] * K[j * 3 + k]; ktg += K[k * 3 + i] * G[k * 3 + j]; }
+            dK[i * 3 + j] = s * G[i * 3 + j] + omc * (gkt + ktg);
+        }
+    const float du[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    dth -= (du[0] * r[0] + du[1] * r[1] + du[2] * r[2]) / (th * th);
+    const float e[3] = {ex, ey, ez};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dr[i] = du[i] / th + dth * e[i] / th;
+}
+
+__global__ __launch_bounds__(64) void flame_bwd_chain(FlameDev m, int B, const float* __restrict__ shape, int ns_in,
+                                                      const float* __restrict__ expr, int ne_in, const float* __restrict__ gpose,
+                                                      const float* __restrict__ neck, const float* __restrict__ jaw,
+                                                      const float* __restrict__ eye, const float* __restrict__ dA,
+                                                      const float* __restrict__ dcoef, float* __restrict__ d_shape,
+                                                      float* __restrict__ d_exp, float* __restrict__ d_gpose,
+                                                      float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eye) {
+    __shared__ float sb[1024];
+    __shared__ float sdJ[15];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int nb = m.n_shape + m.n_exp;
+    for (int k = lane; k < nb; k += 64) {
+        float v = 0.f;
+        if (k < m.n_shape) v = (k < ns_in) ? shape[(size_t)b * ns_in + k] : 0.f;
+        else { const int e = k - m.n_shape; v = (e < ne_in) ? expr[(size_t)b * ne_in + e] : 0.f; }
+        sb[k] = v;
+    }
+    __syncthreads();
+    float J[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        float p = 0.f;
+        const float* jd = m.jdirs + (size_t)j * nb;
+        for (int k = lane; k < nb; k += 64) p = fmaf(jd[k], sb[k], p);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        J[j] = m.jtemplate[j] + p;
+    }
+    if (lane == 0) {
+        float pose[15];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { pose[i] = gpose[b * 3 + i]; pose[3 + i] = neck ? neck[b * 3 + i] : 0.f; pose[6 + i] = jaw[b * 3 + i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[9 + i] = eye ? eye[b * 6 + i] : 0.f;
+        float R[5][9], Racc[5][9];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) rodrigues(pose + 3 * j, R[j]);
+        const int parent[5] = {-1, 0, 1, 1, 1};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Racc[0][i] = R[0][i];
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            const int p = parent[j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Racc[j][r * 3 + c] = Racc[p][r * 3] * R[j][c] + Racc[p][r * 3 + 1] * R[j][3 + c] + Racc[p][r * 3 + 2] * R[j][6 + c];
+        }
+        float dRacc[5][9], dt[5][3], dJ[15], dR[5][9];
+        const float* dAb = dA + (size_t)b * 60;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) dJ[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float dta = dAb[j * 12 + r * 4 + 3];
+                dt[j][r] = dta;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dRacc[j][r * 3 + c] = dAb[j * 12 + r * 4 + c] - dta * J[j * 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)                           // dJ_j -= Racc_j^T dta
+                dJ[j * 3 + c] -= Racc[j][c] * dAb[j * 12 + 3] + Racc[j][3 + c] * dAb[j * 12 + 7] + Racc[j][6 + c] * dAb[j * 12 + 11];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) dR[j][i] = 0.f;
+        }
+        const float* dpf = dcoef + (size_t)b * m.KP + nb;         // pose-feature gradients (R_j - I), j = 1..4
+#pragma unroll
+        for (int j = 4; j >= 1; --j) {
+            const int p = parent[j];
+            float rel[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rel[i] = J[j * 3 + i] - J[p * 3 + i];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dRacc[p][r * 3 + c] += dt[j][r] * rel[c];       // t_j = Racc_p rel + t_p
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float drel = Racc[p][c] * dt[j][0] + Racc[p][3 + c] * dt[j][1] + Racc[p][6 + c] * dt[j][2];
+                dJ[j * 3 + c] += drel; dJ[p * 3 + c] -= drel;
+                dt[p][c] += dt[j][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {                       // Racc_j = Racc_p R_j
+                    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { a1 += dRacc[j][r * 3 + k] * R[j][c * 3 + k]; a2 += Racc[p][k * 3 + r] * dRacc[j][k * 3 + c]; }
+                    dRacc[p][r * 3 + c] += a1;
+                    dR[j][r * 3 + c] += a2 + dpf[(j - 1) * 9 + r * 3 + c];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dR[0][i] += dRacc[0][i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dJ[c] += dt[0][c];
+        float dpose[15];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) rodrigues_bwd(pose + 3 * j, dR[j], dpose + 3 * j);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            d_gpose[b * 3 + i] = dpose[i];
+            if (d_neck) d_neck[b * 3 + i] = dpose[3 + i];
+            d_jaw[b * 3 + i] = dpose[6 + i];
+        }
+        if (d_eye) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d_eye[b * 6 + i] = dpose[9 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) sdJ[i] = dJ[i];
+    }
+    __syncthreads();
+    for (int k = lane; k < nb; k += 64) {
+        float g = dcoef[(size_t)b * m.KP + k];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) g = fmaf(m.jdirs[(size_t)j * nb + k], sdJ[j], g);
+        if (k < m.n_shape) { if (k < ns_in) d_shape[(size_t)b * ns_in + k] = g; }
+        else { const int e = k - m.n_shape; if (e < ne_in) d_exp[(size_t)b * ne_in + e] = g; }
+    }
+}
+
 static FlameDev to_dev(const SmirkFlameModel* m) {
     FlameDev d;
     d.V = m->V; d.VP = m->VP; d.F = m->F; d.n_shape = m->n_shape; d.n_exp = m->n_exp; d.KP = m->KP;
@@ -304,8 +570,8 @@ extern "C" size_t smirk_flame_workspace_bytes(const SmirkFlameModel* m, int B) {
 extern "C" int smirk_flame_forward(const SmirkFlameModel* m, int B, const float* shape, int ns_in, const float* expr,
                                    int ne_in, const float* global_pose, const float* neck, const float* jaw,
                                    const float* eye, const float* eyelid, float* verts, float* lmk_fan,
-                                   float* lmk_fan3d, float* lmk_mp, int32_t* lut_idx_out, void* ws, size_t ws_bytes,
-                                   void* stream) {
+                                   float* lmk_fan3d, float* lmk_mp, int32_t* lut_idx_out, float* v_posed_out, void* ws,
+                                   size_t ws_bytes, void* stream) {
     if (!m || B <= 0 || !shape || !expr || !global_pose || !jaw || !verts || !lmk_fan || !lmk_fan3d || !lmk_mp || !ws)
         return SMIRK_ERR_BAD_ARG;
     if (m->KP % FL_BK || m->VP % FL_BV || m->VP < m->V || m->n_shape + m->n_exp + 36 > m->KP ||
@@ -321,7 +587,7 @@ extern "C" int smirk_flame_forward(const SmirkFlameModel* m, int B, const float*
     hipLaunchKernelGGL(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw,
                        eye, coef, amat, lut);
     dim3 grid(m->VP / FL_BV, (B + FL_BM - 1) / FL_BM);
-    hipLaunchKernelGGL(flame_blend_skin, grid, dim3(256), 0, st, d, B, coef, amat, eyelid, verts);
+    hipLaunchKernelGGL(flame_blend_skin, grid, dim3(256), 0, st, d, B, coef, amat, eyelid, verts, v_posed_out);
     hipLaunchKernelGGL(flame_landmarks, dim3(B), dim3(256), 0, st, d, B, verts, lut, lmk_fan, lmk_fan3d, lmk_mp);
     if (lut_idx_out) {
         hipError_t e = hipMemcpyAsync(lut_idx_out, lut, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
@@ -336,5 +602,56 @@ extern "C" int smirk_vertices2landmarks(const float* verts, int B, int V, const 
     const size_t n = (size_t)B * L;
     hipLaunchKernelGGL(v2l_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, B, V,
                        faces, faces_idx, bary, L, out);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* in1, const float* w, const float* scale,
+                                    const float* shift, const float* residual, float* out, void* stream);
+
+static size_t bwd_off(size_t& cur, size_t bytes) { const size_t o = cur; cur += smirk_align_up(bytes, 256); return o; }
+
+extern "C" size_t smirk_flame_backward_workspace_bytes(const SmirkFlameModel* m, int B) {
+    if (!m || B <= 0) return 0;
+    size_t cur = smirk_flame_workspace_bytes(m, B);
+    bwd_off(cur, (size_t)B * m->V * 12);        // G
+    bwd_off(cur, (size_t)B * 3 * m->VP * 4);    // gvp planar
+    bwd_off(cur, (size_t)B * 60 * 4);           // dA
+    bwd_off(cur, (size_t)B * m->KP * 4);        // dcoef
+    return cur;
+}
+
+extern "C" int smirk_flame_backward(const SmirkFlameModel* m, const float* dirs_t, int B, const float* shape, int ns_in,
+                                    const float* expr, int ne_in, const float* global_pose, const float* neck, const float* jaw,
+                                    const float* eye, const float* eyelid, const float* v_posed, const int32_t* lut_idx,
+                                    const float* g_verts, const float* g_fan, const float* g_fan3d, const float* g_mp,
+                                    float* d_shape, float* d_exp, float* d_gpose, float* d_neck, float* d_jaw, float* d_eye,
+                                    float* d_eyelid, void* ws, size_t ws_bytes, void* stream) {
+    if (!m || !dirs_t || B <= 0 || !shape || !expr || !global_pose || !jaw || !v_posed || !lut_idx || !d_shape || !d_exp || !d_gpose ||
+        !d_jaw || !ws || (eyelid && !d_eyelid))
+        return SMIRK_ERR_BAD_ARG;
+    if (ws_bytes < smirk_flame_backward_workspace_bytes(m, B)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const FlameDev d = to_dev(m);
+    char* base = (char*)ws;
+    float* coef = (float*)base;
+    float* amat = (float*)(base + smirk_align_up((size_t)B * m->KP * 4, 256));
+    int32_t* lut = (int32_t*)((char*)amat + smirk_align_up((size_t)B * 60 * 4, 256));
+    size_t cur = smirk_flame_workspace_bytes(m, B);
+    float* G = (float*)(base + bwd_off(cur, (size_t)B * m->V * 12));
+    float* gvp = (float*)(base + bwd_off(cur, (size_t)B * 3 * m->VP * 4));
+    float* dA = (float*)(base + bwd_off(cur, (size_t)B * 60 * 4));
+    float* dcoef = (float*)(base + bwd_off(cur, (size_t)B * m->KP * 4));
+    // forward quantities (coefficient rows, joint transforms) are recomputed rather than stored
+    hipLaunchKernelGGL(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw, eye, coef, amat, lut);
+    hipLaunchKernelGGL(flame_bwd_gather, dim3(B), dim3(256), 0, st, d, B, g_verts, g_fan, g_fan3d, g_mp, lut_idx, G);
+    hipLaunchKernelGGL(flame_bwd_skin, dim3(B), dim3(256), 0, st, d, B, (const float*)G, v_posed, (const float*)amat, eyelid, gvp, dA,
+                       d_eyelid ? d_eyelid : dcoef /* scratch: dcoef is written by the GEMM afterwards */);
+    SmirkConvDesc cd;
+    cd.B = B; cd.H = 1; cd.W = 1; cd.C0 = 3 * m->VP; cd.C1 = 0; cd.Cout = m->KP; cd.KH = 1; cd.KW = 1; cd.stride = 1; cd.pad_t = 0; cd.pad_l = 0;
+    cd.Ho = 1; cd.Wo = 1; cd.pad_mode = SMIRK_PAD_ZERO; cd.act = SMIRK_ACT_NONE; cd.out_mode = SMIRK_OUT_NHWC;
+    const int rc = smirk_conv_igemm_f32(&cd, gvp, nullptr, dirs_t, nullptr, nullptr, nullptr, dcoef, stream);
+    if (rc != SMIRK_OK) return rc;
+    hipLaunchKernelGGL(flame_bwd_chain, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw, eye,
+                       (const float*)dA, (const float*)dcoef, d_shape, d_exp, d_gpose, d_neck, d_jaw, d_eye);
     return smirk_launch_status();
 }

@@ -228,3 +228,17 @@ def test_masking_oracle_vs_reference_golden(sandbox, golden_dir):
     assert np.abs(masked[:, :, ::2, ::2] - g["masked_sub2"]).max() < 1e-6
     tp = MR.transfer_pixels(img, g["npoints"], g["npoints"][:, ::-1])
     assert int((tp != 0).sum()) == int(g["transfer_nonzero"]) and abs(tp.astype(np.float64).sum() - float(g["transfer_sum"])) < 1e-3
+
+
+def test_flame_gradient_oracle_vs_reference_golden(sandbox, golden_dir):
+    """oracle/flame_torch_ref.py autograd == autograd through the real reference FLAME."""
+    import torch
+    from oracle.flame_torch_ref import FlameTorchRef, scalar_loss
+    g = np.load(os.path.join(golden_dir, "flame_grad_golden.npz"))
+    tp = {k[3:]: torch.from_numpy(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("in_")}
+    loss, _ = scalar_loss(FlameTorchRef(sandbox)(tp), seed=int(g["loss_seed"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * max(1.0, abs(float(g["loss"])))
+    for k, v in tp.items():
+        ref = g["d_" + k]
+        assert np.abs(v.grad.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k

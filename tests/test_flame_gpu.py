@@ -101,3 +101,80 @@ def test_cpu_tensor_raises(flame):
     p = {k: torch.from_numpy(v) for k, v in A.synth_flame_params(1).items()}
     with pytest.raises(SmirkHipError):
         flame.forward(p)
+
+
+# ---- backward pass: smirk_flame_backward vs autograd through the reference ------------------------------------------
+GRAD_RTOL = 2e-5        # relative to max(1, largest |gradient| of that parameter); measured 4e-6 (torch CPU fp32 itself: 4e-7)
+
+
+def _hip_grads(flame, p, loss_seed, keys=None, only=None):
+    from oracle.flame_torch_ref import scalar_loss
+    tp = {k: torch.from_numpy(v).cuda().requires_grad_(keys is None or k in keys) for k, v in p.items()}
+    out = flame.forward(tp)
+    cpu_like = {k: v for k, v in out.items()}
+    # same random functional as the oracle: weights generated on the CPU, moved to the device
+    _, ws = scalar_loss({k: v.detach().cpu() for k, v in cpu_like.items()}, seed=loss_seed)
+    loss = sum((out[k] * ws[k].cuda()).sum() for k in ws if only is None or k in only)
+    loss.backward()
+    torch.cuda.synchronize()
+    return {k: v.grad.cpu().numpy() for k, v in tp.items() if v.grad is not None}, {k: v.detach().cpu().numpy() for k, v in out.items()}
+
+
+def _oracle_grads(sandbox, p, loss_seed, only=None, dtype=torch.float64):
+    from oracle.flame_torch_ref import FlameTorchRef, scalar_loss
+    tp = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in p.items()}
+    out = FlameTorchRef(sandbox, dtype=dtype)(tp)
+    _, ws = scalar_loss({k: v.detach().float() for k, v in out.items()}, seed=loss_seed)
+    loss = sum((out[k] * ws[k].to(dtype)).sum() for k in ws if only is None or k in only)
+    loss.backward()
+    return {k: v.grad.numpy() for k, v in tp.items()}
+
+
+def _cmp_grads(got, ref, keys=None):
+    for k in (keys or ref.keys()):
+        scale = max(1.0, np.abs(ref[k]).max())
+        err = np.abs(got[k] - ref[k]).max() / scale
+        assert err < GRAD_RTOL, (k, err)
+
+
+def test_flame_backward_matches_reference_autograd_golden(flame, golden_dir):
+    g = np.load(os.path.join(golden_dir, "flame_grad_golden.npz"))
+    p = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    got, _ = _hip_grads(flame, p, int(g["loss_seed"]))
+    _cmp_grads(got, {k: g["d_" + k] for k in p})
+
+
+@pytest.mark.parametrize("B", [1, 5, 128])
+def test_flame_backward_matches_oracle_autograd_f64(flame, sandbox, B):
+    p = A.synth_flame_params(B, seed=100 + B)
+    p["neck_pose_params"] = (0.1 * np.random.default_rng(B).standard_normal((B, 3))).astype(np.float32)
+    p["eye_pose_params"] = (0.1 * np.random.default_rng(B + 1).standard_normal((B, 6))).astype(np.float32)
+    ref = _oracle_grads(sandbox, p, 7)
+    got, _ = _hip_grads(flame, p, 7)
+    _cmp_grads(got, ref)
+
+
+def test_flame_backward_partial_paths(flame, sandbox):
+    """only landmark losses / only some inputs requiring grad / no eyelid term / truncated coefficient vectors"""
+    p = A.synth_flame_params(4, seed=77)
+    only = ("landmarks_fan", "landmarks_mp")
+    ref = _oracle_grads(sandbox, p, 9, only=only)
+    got, _ = _hip_grads(flame, p, 9, only=only)
+    _cmp_grads(got, ref)
+    got, _ = _hip_grads(flame, p, 9, keys=("expression_params", "jaw_params"), only=only)
+    assert set(got) == {"expression_params", "jaw_params"}
+    _cmp_grads(got, ref, keys=got.keys())
+    q = {k: v for k, v in p.items() if k != "eyelid_params"}
+    q["shape_params"], q["expression_params"] = q["shape_params"][:, :100].copy(), q["expression_params"][:, :20].copy()
+    ref = _oracle_grads(sandbox, q, 11)
+    got, _ = _hip_grads(flame, q, 11)
+    assert got["shape_params"].shape == (4, 100) and got["expression_params"].shape == (4, 20)
+    _cmp_grads(got, ref)
+
+
+def test_flame_forward_unchanged_when_differentiable(flame):
+    p = A.synth_flame_params(6, seed=5)
+    base = _run(flame, p)
+    _, out = _hip_grads(flame, p, 1)
+    for k in out:
+        assert np.array_equal(out[k], base[k]), k
