@@ -141,6 +141,23 @@ int smirk_vertex_normals(const SmirkRenderMesh* mesh, int B, const float* verts,
 /* Landmark projection (renderer.py:104-108): lmk[B][L][3], cam[B][3] -> out[B][L][2]. */
 int smirk_project_landmarks(const float* lmk, const float* cam, int B, int L, float* out, void* stream);
 
+/* Backward of smirk_render_forward — replaces autograd through Renderer.forward (renderer.py:100-207,239-250; util.py:30-78) plus
+ * pytorch3d's RasterizeMeshes backward for blur_radius=0, faces_per_pixel=1, perspective_correct=False (gradient of the barycentric
+ * weights only; pix_to_face / zbuf / dists carry none in the reference).  pix_to_face: the forward call's optional output.
+ * g_img[B][3][H][W] (nullable) = dL/drendered_img, g_transformed[B][V][3] (nullable) = dL/dtransformed_vertices.
+ * Writes d_verts[B][V][3] (zero outside the face region unless g_transformed is given) and d_cam[B][3] (overwritten).
+ * Deterministic: no atomics, fixed summation order. */
+size_t smirk_render_backward_workspace_bytes(const SmirkRenderMesh* mesh /*host struct*/, int B, int H, int W);
+int smirk_render_backward(const SmirkRenderMesh* mesh, int B, int H, int W,
+                          const float* verts, const float* cam, const int64_t* pix_to_face,
+                          const float* g_img, const float* g_transformed,
+                          float* d_verts, float* d_cam, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of smirk_project_landmarks: g_out[B][L][2] -> d_lmk[B][L][3] (written), d_cam_accum[B][3] (ADDED to: call after
+ * smirk_render_backward, or on a zeroed buffer). */
+int smirk_project_landmarks_backward(const float* lmk, const float* cam, const float* g_out, int B, int L,
+                                     float* d_lmk, float* d_cam_accum, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Convolution building blocks (fp32 MFMA implicit GEMM, NHWC) — replace the cuDNN/ATen kernels the reference reaches
  * through nn.Conv2d / nn.ConvTranspose2d / nn.BatchNorm2d(eval) / ReLU / MaxPool2d / ReflectionPad2d

@@ -3,11 +3,13 @@
 Regenerates tests/golden/*.npz by running the REAL reference classes (imported from /root/reference through
 oracle/sandbox.py) on seeded synthetic inputs.  Runs only in the build container; the fixtures travel to the GPU box.
 
-    python -m oracle.make_golden            # writes tests/golden/{assets_bundle,flame,flame_grad,render,generator,encoder,masking}_golden.npz
+    python -m oracle.make_golden            # writes tests/golden/{assets_bundle,flame,flame_grad,render,render_grad,generator,encoder,masking}_golden.npz
 
 What each fixture pins
   flame_golden      reference FLAME.forward (FLAME.py:232-315) outputs, B=4                      -> fully pinned
   flame_grad_golden autograd through the reference FLAME.forward of a fixed random linear loss, B=3 -> fully pinned
+  render_grad_golden autograd through the reference Renderer.forward (normals, shading, projection pinned; barycentric backward =
+                    autograd of the pytorch3d formula, PARITY UNPINNED)
   generator_golden  reference SmirkGenerator(6,3,32,5).eval() (smirk_generator.py:51-86), B=1    -> fully pinned
   render_golden     reference Renderer.forward (renderer.py:100-207) on top of oracle/raster_ref.c -> glue pinned,
                     rasteriser itself PARITY UNPINNED (pytorch3d not on disk)
@@ -116,6 +118,23 @@ def main():
         loss.backward()
         np.savez_compressed(os.path.join(GOLD, "flame_grad_golden.npz"), seed=17, loss_seed=3, loss=np.float64(loss.item()),
                             **{"in_" + k: v for k, v in p.items()}, **{"d_" + k: v.grad.numpy() for k, v in tp.items()})
+    # ---- Renderer gradients (§8 f-2): autograd through the REAL reference Renderer.forward; the pytorch3d shim supplies visibility from
+    #      oracle/raster_ref.c and differentiable barycentrics from oracle/render_torch_ref.py (third-party part PARITY UNPINNED) ----
+    from . import render_torch_ref as RT
+    from .flame_ref import FlameRef
+    with S.reference(d) as ref:
+        rn = ref.Renderer()
+        fo = FlameRef(d).forward(A.synth_flame_params(2, seed=23))
+        cam = A.synth_cam(2, seed=23)
+        leaf = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True)
+        v, c, lf, lm = leaf(fo["vertices"]), leaf(cam), leaf(fo["landmarks_fan"]), leaf(fo["landmarks_mp"])
+        o = rn.forward(v, c, landmarks_fan=lf, landmarks_mp=lm)
+        loss, _ = RT.scalar_loss(o, seed=29)
+        loss.backward()
+        np.savez_compressed(os.path.join(GOLD, "render_grad_golden.npz"), loss_seed=29, loss=np.float64(loss.item()),
+                            in_vertices=v.detach().numpy(), in_cam=c.detach().numpy(), in_landmarks_fan=lf.detach().numpy(),
+                            in_landmarks_mp=lm.detach().numpy(), d_vertices=v.grad.numpy(), d_cam=c.grad.numpy(),
+                            d_landmarks_fan=lf.grad.numpy(), d_landmarks_mp=lm.grad.numpy())
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
 

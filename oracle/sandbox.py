@@ -70,10 +70,19 @@ def _install_shims():
         B, Ff = meshes.num_meshes(), meshes.num_faces_per_mesh()
         p2f, zbuf, bary = R.rasterize_naive(fv.reshape(B, Ff, 3, 3), image_size, image_size)
         p2f = p2f.astype(np.int64)
+        bary_t = torch.from_numpy(bary)
+        vpk = meshes.verts_packed()
+        if vpk.requires_grad:
+            # differentiable barycentrics (oracle/render_torch_ref.py): forward values stay the C rasteriser's, the gradient is
+            # autograd of pytorch3d's formula — what its BarycentricCoordsBackward computes analytically.
+            from .render_torch_ref import bary_differentiable
+            fvt = vpk[meshes.faces_packed()].reshape(B, Ff, 3, 3)
+            bd = bary_differentiable(fvt, torch.from_numpy(p2f), image_size, image_size)
+            bary_t = bary_t + (bd - bd.detach())
         off = (np.arange(B, dtype=np.int64) * Ff)[:, None, None]
         p2f = np.where(p2f >= 0, p2f + off, -1)
         return (torch.from_numpy(p2f)[..., None], torch.from_numpy(zbuf)[..., None],
-                torch.from_numpy(bary)[:, :, :, None, :], torch.full(p2f.shape + (1,), -1.0))
+                bary_t[:, :, :, None, :], torch.full(p2f.shape + (1,), -1.0))
 
     p3d = types.ModuleType("pytorch3d")
     st = types.ModuleType("pytorch3d.structures"); st.Meshes = Meshes

@@ -58,6 +58,9 @@ _SIGS = {
     "smirk_maxpool_sq": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_bernoulli_field": (_i, [_p, _sz, C.c_float, C.c_uint64, C.c_uint64, _p]),
     "smirk_masking_compose": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint64, _p, _p]),
+    "smirk_render_backward_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
+    "smirk_render_backward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "smirk_project_landmarks_backward": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "smirk_rendered_mask": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "smirk_scatter_points_mask": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "smirk_transfer_pixels": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),

@@ -91,6 +91,27 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 }
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
 
+// conservative pixel-index box (xi0,xi1,yi0,yi1) of a face record; empty (xi0 > xi1) for faces the reference skips wholesale
+__device__ inline short4 face_pixel_box(const float* p, int H, int W) {
+    const float xmin = fminf(p[0], fminf(p[3], p[6])), xmax = fmaxf(p[0], fmaxf(p[3], p[6]));
+    const float ymin = fminf(p[1], fminf(p[4], p[7])), ymax = fmaxf(p[1], fmaxf(p[4], p[7]));
+    const float zmax = fmaxf(p[2], fmaxf(p[5], p[8]));
+    const float area = edge_fn(p[0], p[1], p[3], p[4], p[6], p[7]);
+    short4 box = make_short4(1, 0, 1, 0);
+    const bool finite = (xmin == xmin) && (xmax == xmax) && (ymin == ymin) && (ymax == ymax);
+    if (finite && fabsf(area) > K_EPS && !(zmax < K_EPS)) {
+        // pixel column xi sees ndc(W-1-xi); ndc(i) = -1 + (2i+1)/W  =>  i in [ (W(xmin+1)-1)/2 , (W(xmax+1)-1)/2 ], widened by 1
+        float ilo = floorf((W * (xmin + 1.0f) - 1.0f) * 0.5f) - 1.0f, ihi = ceilf((W * (xmax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
+        float jlo = floorf((H * (ymin + 1.0f) - 1.0f) * 0.5f) - 1.0f, jhi = ceilf((H * (ymax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
+        ilo = fminf(fmaxf(ilo, 0.f), (float)(W - 1)); ihi = fminf(fmaxf(ihi, -1.f), (float)(W - 1));
+        jlo = fminf(fmaxf(jlo, 0.f), (float)(H - 1)); jhi = fminf(fmaxf(jhi, -1.f), (float)(H - 1));
+        if (!(xmax < -1.0f || xmin > 1.0f || ymax < -1.0f || ymin > 1.0f))
+            box = make_short4((short)(W - 1 - (int)ihi), (short)(W - 1 - (int)ilo), (short)(H - 1 - (int)jhi),
+                              (short)(H - 1 - (int)jlo));
+    }
+    return box;
+}
+
 // face record: 9 floats (x0,y0,z0,x1,y1,z1,x2,y2,z2) in pytorch3d NDC;  bbox: conservative pixel-index box (xi0,xi1,yi0,yi1),
 // empty (xi0 > xi1) for faces the reference skips wholesale (|area| <= eps, zmax < eps).
 __global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H, int W, const float* __restrict__ tv,
@@ -109,22 +130,7 @@ __global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) frec[i * 9 + k] = p[k];
-    const float xmin = fminf(p[0], fminf(p[3], p[6])), xmax = fmaxf(p[0], fmaxf(p[3], p[6]));
-    const float ymin = fminf(p[1], fminf(p[4], p[7])), ymax = fmaxf(p[1], fmaxf(p[4], p[7]));
-    const float zmax = fmaxf(p[2], fmaxf(p[5], p[8]));
-    const float area = edge_fn(p[0], p[1], p[3], p[4], p[6], p[7]);
-    short4 box = make_short4(1, 0, 1, 0);
-    const bool finite = (xmin == xmin) && (xmax == xmax) && (ymin == ymin) && (ymax == ymax);
-    if (finite && fabsf(area) > K_EPS && !(zmax < K_EPS)) {
-        // pixel column xi sees ndc(W-1-xi); ndc(i) = -1 + (2i+1)/W  =>  i in [ (W(xmin+1)-1)/2 , (W(xmax+1)-1)/2 ], widened by 1
-        float ilo = floorf((W * (xmin + 1.0f) - 1.0f) * 0.5f) - 1.0f, ihi = ceilf((W * (xmax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
-        float jlo = floorf((H * (ymin + 1.0f) - 1.0f) * 0.5f) - 1.0f, jhi = ceilf((H * (ymax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
-        ilo = fminf(fmaxf(ilo, 0.f), (float)(W - 1)); ihi = fminf(fmaxf(ihi, -1.f), (float)(W - 1));
-        jlo = fminf(fmaxf(jlo, 0.f), (float)(H - 1)); jhi = fminf(fmaxf(jhi, -1.f), (float)(H - 1));
-        if (!(xmax < -1.0f || xmin > 1.0f || ymax < -1.0f || ymin > 1.0f))
-            box = make_short4((short)(W - 1 - (int)ihi), (short)(W - 1 - (int)ilo), (short)(H - 1 - (int)jhi),
-                              (short)(H - 1 - (int)jlo));
-    }
+    const short4 box = face_pixel_box(p, H, W);
     fbox[i] = box;
 }
 
@@ -260,6 +266,277 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
     const size_t smem = FACE_CHUNK * 9 * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
     hipLaunchKernelGGL(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
                        (long long*)pix_to_face, bary, zbuf);
+    return smirk_launch_status();
+}
+
+// ====================================================================================================================================
+// Backward pass: dL/dvertices, dL/dcam from dL/drendered_img (+ optional dL/dtransformed_vertices) — what autograd
+// through Renderer.forward + pytorch3d's RasterizeMeshes backward produce in the reference's training step (smirk_trainer.py:46-48,362).
+// Visibility carries no gradient; the barycentric weights do (geometry_utils.cuh BarycentricCoordsBackward = the analytic derivative of
+// w_k = e_k / (area + 1e-8)), as do the interpolated vertex normals through shading.  All sums are gathers in a fixed order: the
+// gradients are bit-reproducible run to run (pytorch3d's atomicAdd backward is not).
+//   render_bwd_faces    one lane per (image, face): walk the face's pixel box, for pixels it owns accumulate the gradients of its 3
+//                       screen-space corners (bary path) and of its 3 corner normals (shading path)            -> fgrad[B][Ff][15]
+//   render_bwd_normals  one lane per kept vertex: gather corner-normal gradients (CSR), F.normalize backward     -> dS[B][Vf][3]
+//   render_bwd_vertices one workgroup per image: gather screen gradients + cross-product backward per vertex, un-project through the
+//                       camera, reduce dL/dcam                                                                     -> d_verts, d_cam
+// ====================================================================================================================================
+#define FG 15
+__global__ __launch_bounds__(256) void render_bwd_faces(MeshDev m, int B, int H, int W, const float* __restrict__ verts,
+                                                        const float* __restrict__ cam, const float* __restrict__ normals,
+                                                        const long long* __restrict__ p2f, const float* __restrict__ g_img,
+                                                        float* __restrict__ fgrad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * m.Ff) return;
+    const int b = (int)(i / m.Ff), f = (int)(i % m.Ff);
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+    const float* vb = verts + (size_t)b * m.V * 3;
+    const float* nb = normals + (size_t)b * m.Vf * 3;
+    float p[9], N[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int lv = m.faces[f * 3 + k], g = m.keep[lv];
+        // same operation sequence as render_project + raster_face_setup so that the box and the weights match the forward pass
+        p[k * 3 + 0] = -(s * (vb[g * 3 + 0] + tx));
+        p[k * 3 + 1] = -(-(s * (vb[g * 3 + 1] + ty)));
+        p[k * 3 + 2] = -(s * vb[g * 3 + 2]) + 10.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) N[k * 3 + c] = nb[lv * 3 + c];
+    }
+    float acc[FG];
+#pragma unroll
+    for (int k = 0; k < FG; ++k) acc[k] = 0.f;
+    const short4 box = face_pixel_box(p, H, W);
+    const float x0 = p[0], y0 = p[1], x1 = p[3], y1 = p[4], x2 = p[6], y2 = p[7];
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+    const float grey = 180.0f / 255.0f, q = 0.57735026918962576f;
+    const float lx[5] = {-q, q, -q, q, 0.f}, ly[5] = {q, q, -q, -q, 0.f}, lz[5] = {q, q, q, q, 1.f};
+    const long long me = (long long)b * m.Ff + f;
+    const size_t plane = (size_t)H * W;
+    float g_area = 0.f;
+    for (int yi = box.z; yi <= box.w; ++yi) {
+        const float yf = pix_to_ndc(H - 1 - yi, H);
+        for (int xi = box.x; xi <= box.y; ++xi) {
+            const size_t pix = (size_t)yi * W + xi;
+            if (p2f[(size_t)b * plane + pix] != me) continue;
+            const float xf = pix_to_ndc(W - 1 - xi, W);
+            const float e0 = edge_fn(xf, yf, x1, y1, x2, y2), e1 = edge_fn(xf, yf, x2, y2, x0, y0), e2 = edge_fn(xf, yf, x0, y0, x1, y1);
+            const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+            const float* gi = g_img + (size_t)b * 3 * plane + pix;
+            const float g = (gi[0] + gi[plane]) + gi[2 * plane];
+            float nimg[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nimg[c] = (w0 * N[c] + w1 * N[3 + c]) + w2 * N[6 + c];
+            const float albedo = (w0 * grey + w1 * grey) + w2 * grey;
+            float sh = 0.f, dl[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                const float t = (nimg[0] * lx[l] + nimg[1] * ly[l]) + nimg[2] * lz[l];
+                sh += fminf(fmaxf(t, 0.f), 1.f) * 1.7f;
+                if (t >= 0.f && t <= 1.f) { dl[0] += lx[l]; dl[1] += ly[l]; dl[2] += lz[l]; }     // clamp passes gradient on [0, 1]
+            }
+            sh = sh / 5.0f;
+            const float d_alb = g * sh, d_sh = g * albedo * (1.7f / 5.0f);
+            const float dn[3] = {d_sh * dl[0], d_sh * dl[1], d_sh * dl[2]};
+            const float dw0 = d_alb * grey + ((dn[0] * N[0] + dn[1] * N[1]) + dn[2] * N[2]);
+            const float dw1 = d_alb * grey + ((dn[0] * N[3] + dn[1] * N[4]) + dn[2] * N[5]);
+            const float dw2 = d_alb * grey + ((dn[0] * N[6] + dn[1] * N[7]) + dn[2] * N[8]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { acc[6 + c] += w0 * dn[c]; acc[9 + c] += w1 * dn[c]; acc[12 + c] += w2 * dn[c]; }
+            g_area -= ((dw0 * e0 + dw1 * e1) + dw2 * e2) / (area * area);
+            const float ge0 = dw0 / area, ge1 = dw1 / area, ge2 = dw2 / area;
+            // e0 = E(p; v1, v2), e1 = E(p; v2, v0), e2 = E(p; v0, v1);  dE(p;a,b)/da = (p.y - b.y, b.x - p.x), dE/db = (a.y - p.y, p.x - a.x)
+            acc[0] += ge1 * (y2 - yf) + ge2 * (yf - y1);   acc[1] += ge1 * (xf - x2) + ge2 * (x1 - xf);      // v0
+            acc[2] += ge0 * (yf - y2) + ge2 * (y0 - yf);   acc[3] += ge0 * (x2 - xf) + ge2 * (xf - x0);      // v1
+            acc[4] += ge0 * (y1 - yf) + ge1 * (yf - y0);   acc[5] += ge0 * (xf - x1) + ge1 * (x0 - xf);      // v2
+        }
+    }
+    // area = E(v2; v0, v1) + eps
+    acc[0] += g_area * (y2 - y1); acc[1] += g_area * (x1 - x2);
+    acc[2] += g_area * (y0 - y2); acc[3] += g_area * (x2 - x0);
+    acc[4] += g_area * (y1 - y0); acc[5] += g_area * (x0 - x1);
+#pragma unroll
+    for (int k = 0; k < FG; ++k) fgrad[i * FG + k] = acc[k];
+}
+
+__global__ __launch_bounds__(256) void render_bwd_normals(MeshDev m, int B, const float* __restrict__ verts,
+                                                          const float* __restrict__ fgrad, float* __restrict__ dS) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * m.Vf) return;
+    const int b = (int)(i / m.Vf), vi = (int)(i % m.Vf);
+    const float* vb = verts + (size_t)b * m.V * 3;
+    const float* fg = fgrad + (size_t)b * m.Ff * FG;
+    float n[3] = {0.f, 0.f, 0.f}, dN[3] = {0.f, 0.f, 0.f};
+    for (int e = m.nrm_ptr[vi]; e < m.nrm_ptr[vi + 1]; ++e) {
+        const int f = m.nrm_face[e], c = m.nrm_corner[e];
+        float p[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int g = m.keep[m.faces[f * 3 + k]];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) p[k][d] = vb[g * 3 + d];
+        }
+        const int i0 = c, i1 = (c + 1) % 3, i2 = (c + 2) % 3;
+        float a[3], bb[3], cr[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { a[d] = p[i1][d] - p[i0][d]; bb[d] = p[i2][d] - p[i0][d]; }
+        cross3(a, bb, cr);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { n[d] += cr[d]; dN[d] += fg[(size_t)f * FG + 6 + c * 3 + d]; }
+    }
+    const float nrm = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    float* o = dS + i * 3;
+    if (nrm >= 1e-6f) {                                      // N = S / |S|:  dS = (dN - N (N.dN)) / |S|
+        const float N0 = n[0] / nrm, N1 = n[1] / nrm, N2 = n[2] / nrm;
+        const float dot = (N0 * dN[0] + N1 * dN[1]) + N2 * dN[2];
+        o[0] = (dN[0] - N0 * dot) / nrm; o[1] = (dN[1] - N1 * dot) / nrm; o[2] = (dN[2] - N2 * dot) / nrm;
+    } else {                                                 // N = S / eps
+        o[0] = dN[0] / 1e-6f; o[1] = dN[1] / 1e-6f; o[2] = dN[2] / 1e-6f;
+    }
+}
+
+__device__ inline void block_reduce3(float* v, float* red /*[3][4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) red[k * 4 + wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = (red[k * 4 + 0] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+    __syncthreads();
+}
+
+// d_verts / d_cam initialisation with the (optional) gradient of `transformed_vertices` itself
+__global__ __launch_bounds__(256) void render_bwd_init(int B, int V, const float* __restrict__ verts, const float* __restrict__ cam,
+                                                       const float* __restrict__ g_tv, float* __restrict__ d_verts,
+                                                       float* __restrict__ d_cam) {
+    __shared__ float red[12];
+    const int b = blockIdx.x;
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+    float dc[3] = {0.f, 0.f, 0.f};
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const size_t o = ((size_t)b * V + v) * 3;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (g_tv) { g0 = g_tv[o]; g1 = g_tv[o + 1]; g2 = g_tv[o + 2]; }
+        d_verts[o] = s * g0; d_verts[o + 1] = -(s * g1); d_verts[o + 2] = -(s * g2);
+        dc[0] += ((verts[o] + tx) * g0 - (verts[o + 1] + ty) * g1) - verts[o + 2] * g2;
+        dc[1] += s * g0; dc[2] -= s * g1;
+    }
+    block_reduce3(dc, red);
+    if (threadIdx.x < 3) d_cam[b * 3 + threadIdx.x] = dc[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void render_bwd_vertices(MeshDev m, int B, const float* __restrict__ verts,
+                                                           const float* __restrict__ cam, const float* __restrict__ fgrad,
+                                                           const float* __restrict__ dS, float* __restrict__ d_verts,
+                                                           float* __restrict__ d_cam) {
+    __shared__ float red[12];
+    const int b = blockIdx.x;
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+    const float* vb = verts + (size_t)b * m.V * 3;
+    const float* fg = fgrad + (size_t)b * m.Ff * FG;
+    const float* dSb = dS + (size_t)b * m.Vf * 3;
+    float dc[3] = {0.f, 0.f, 0.f};
+    for (int vi = threadIdx.x; vi < m.Vf; vi += 256) {
+        float gsx = 0.f, gsy = 0.f, dv[3] = {0.f, 0.f, 0.f};
+        for (int e = m.nrm_ptr[vi]; e < m.nrm_ptr[vi + 1]; ++e) {
+            const int f = m.nrm_face[e], c = m.nrm_corner[e];
+            gsx += fg[(size_t)f * FG + c * 2]; gsy += fg[(size_t)f * FG + c * 2 + 1];
+            const int l1 = m.faces[f * 3 + (c + 1) % 3], l2 = m.faces[f * 3 + (c + 2) % 3];
+            const int g0i = m.keep[vi], g1i = m.keep[l1], g2i = m.keep[l2];
+            float p0[3], p1[3], p2[3], a[3], bb[3], t[3], u[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { p0[d] = vb[g0i * 3 + d]; p1[d] = vb[g1i * 3 + d]; p2[d] = vb[g2i * 3 + d]; }
+            const float* G0 = dSb + vi * 3; const float* G1 = dSb + l1 * 3; const float* G2 = dSb + l2 * 3;
+            // this vertex's own corner: n = a x b, a = p1 - p0, b = p2 - p0:  d/da = b x G, d/db = G x a, d/dp0 = -(both)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { a[d] = p1[d] - p0[d]; bb[d] = p2[d] - p0[d]; }
+            cross3(bb, G0, t); cross3(G0, a, u);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dv[d] -= t[d] + u[d];
+            // corner at p2: n = (p0 - p2) x (p1 - p2): p0 enters the first factor:  d/dp0 = (p1 - p2) x G2
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a[d] = p1[d] - p2[d];
+            cross3(a, G2, t);
+            // corner at p1: n = (p2 - p1) x (p0 - p1): p0 enters the second factor: d/dp0 = G1 x (p2 - p1)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) bb[d] = p2[d] - p1[d];
+            cross3(G1, bb, u);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dv[d] += t[d] + u[d];
+        }
+        const int g = m.keep[vi];
+        const size_t o = ((size_t)b * m.V + g) * 3;
+        // screen = (-(s (x + tx)), s (y + ty))
+        d_verts[o] += dv[0] - s * gsx;
+        d_verts[o + 1] += dv[1] + s * gsy;
+        d_verts[o + 2] += dv[2];
+        dc[0] += (vb[g * 3 + 1] + ty) * gsy - (vb[g * 3] + tx) * gsx;
+        dc[1] -= s * gsx; dc[2] += s * gsy;
+    }
+    block_reduce3(dc, red);
+    if (threadIdx.x < 3) d_cam[b * 3 + threadIdx.x] += dc[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void project_landmarks_bwd(const float* __restrict__ lmk, const float* __restrict__ cam,
+                                                             const float* __restrict__ g_out, int B, int L,
+                                                             float* __restrict__ d_lmk, float* __restrict__ d_cam) {
+    __shared__ float red[12];
+    const int b = blockIdx.x;
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+    float dc[3] = {0.f, 0.f, 0.f};
+    for (int l = threadIdx.x; l < L; l += 256) {
+        const size_t i = (size_t)b * L + l;
+        const float g0 = g_out[i * 2], g1 = g_out[i * 2 + 1];
+        d_lmk[i * 3] = s * g0; d_lmk[i * 3 + 1] = -(s * g1); d_lmk[i * 3 + 2] = 0.f;
+        dc[0] += (lmk[i * 3] + tx) * g0 - (lmk[i * 3 + 1] + ty) * g1;
+        dc[1] += s * g0; dc[2] -= s * g1;
+    }
+    block_reduce3(dc, red);
+    if (threadIdx.x < 3) d_cam[b * 3 + threadIdx.x] += dc[threadIdx.x];
+}
+
+static size_t ws_fgrad(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Ff * FG * 4, 256); }
+
+extern "C" size_t smirk_render_backward_workspace_bytes(const SmirkRenderMesh* mesh, int B, int H, int W) {
+    if (!mesh || B <= 0) return 0;
+    (void)H; (void)W;
+    return 2 * ws_normals(mesh, B) + ws_fgrad(mesh, B);
+}
+
+extern "C" int smirk_render_backward(const SmirkRenderMesh* mesh, int B, int H, int W, const float* verts, const float* cam,
+                                     const int64_t* pix_to_face, const float* g_img, const float* g_transformed, float* d_verts,
+                                     float* d_cam, void* ws, size_t ws_bytes, void* stream) {
+    if (!mesh || !verts || !cam || !pix_to_face || !d_verts || !d_cam || !ws || B <= 0) return SMIRK_ERR_BAD_ARG;
+    if (H != W || H <= 0 || H > 1024 || mesh->Ff > 65535 || mesh->Ff <= 0) return SMIRK_ERR_UNSUPPORTED;
+    if (ws_bytes < smirk_render_backward_workspace_bytes(mesh, B, H, W)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshDev d = mesh_dev(mesh);
+    char* p = (char*)ws;
+    float* nrm = (float*)p; p += ws_normals(mesh, B);
+    float* dS = (float*)p; p += ws_normals(mesh, B);
+    float* fgrad = (float*)p;
+    const size_t nk = (size_t)B * mesh->Vf, nf = (size_t)B * mesh->Ff;
+    hipLaunchKernelGGL(render_bwd_init, dim3(B), dim3(256), 0, st, B, mesh->V, verts, cam, g_transformed, d_verts, d_cam);
+    if (g_img) {
+        hipLaunchKernelGGL(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
+        hipLaunchKernelGGL(render_bwd_faces, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, verts, cam,
+                           (const float*)nrm, (const long long*)pix_to_face, g_img, fgrad);
+        hipLaunchKernelGGL(render_bwd_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, (const float*)fgrad, dS);
+        hipLaunchKernelGGL(render_bwd_vertices, dim3(B), dim3(256), 0, st, d, B, verts, cam, (const float*)fgrad, (const float*)dS,
+                           d_verts, d_cam);
+    }
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_project_landmarks_backward(const float* lmk, const float* cam, const float* g_out, int B, int L, float* d_lmk,
+                                                float* d_cam_accum, void* stream) {
+    if (!lmk || !cam || !g_out || !d_lmk || !d_cam_accum || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
+    hipLaunchKernelGGL(project_landmarks_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, lmk, cam, g_out, B, L, d_lmk, d_cam_accum);
     return smirk_launch_status();
 }
 

@@ -118,16 +118,35 @@ class Renderer(nn.Module):
         """vertices [B,V,3], cam_params [B,3]=(scale,tx,ty) -> dict(rendered_img [B,3,224,224], transformed_vertices,
         <landmark key> [B,L,2] ...)   (renderer.py:100-118).  `_aux=True` also returns pix_to_face / bary / zbuf / normals."""
         vertices, cam = L.as_f32c(vertices), L.as_f32c(cam_params)
+        if vertices.shape[1] != self._dims['V']:
+            raise L.SmirkHipError("vertex count does not match the template mesh")
+        keys = list(landmarks.keys())
+        lms = [L.as_f32c(landmarks[k]) for k in keys]
+        if torch.is_grad_enabled() and any(t.requires_grad for t in [vertices, cam] + lms):
+            # training step 1 (smirk_trainer.py:46-48,362): image / landmark losses back-propagate to vertices and camera
+            if _aux:
+                raise L.SmirkHipError("_aux outputs are not available on the differentiable path")
+            res = _RenderFunction.apply(self, len(lms), vertices, cam, *lms)
+            out = {'rendered_img': res[0], 'transformed_vertices': res[1]}
+            out.update({k: v for k, v in zip(keys, res[2:])})
+            return out
+        img, tv, proj, aux = self._launch(vertices, cam, lms, _aux, False)
+        out = {'rendered_img': img, 'transformed_vertices': tv}
+        out.update({k: v for k, v in zip(keys, proj)})
+        if _aux:
+            out['_aux'] = aux
+        return out
+
+    def _launch(self, vertices, cam, lms, want_aux, want_p2f):
         B, dev = vertices.shape[0], vertices.device
         H = W = self.image_size
         lib, mesh = L.lib(), self._struct()
-        if vertices.shape[1] != self._dims['V']:
-            raise L.SmirkHipError("vertex count does not match the template mesh")
         tv = torch.empty_like(vertices)
         img = torch.empty(B, 3, H, W, device=dev)
         p2f = bary = zbuf = nrm = None
-        if _aux:
+        if want_aux or want_p2f:
             p2f = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+        if want_aux:
             bary = torch.empty(B, H, W, 3, device=dev)
             zbuf = torch.empty(B, H, W, device=dev)
             nrm = torch.empty(B, self._dims['Vf'], 3, device=dev)
@@ -137,17 +156,56 @@ class Renderer(nn.Module):
         L.check(lib.smirk_render_forward(mesh, B, H, W, P(vertices), P(cam), P(tv), P(img), P(p2f, torch.int64, True),
                                          P(bary, allow_none=True), P(zbuf, allow_none=True), P(nrm, allow_none=True),
                                          P(ws, torch.uint8), nws, L.stream_ptr()))
-        out = {'rendered_img': img, 'transformed_vertices': tv}
-        for key, lm in landmarks.items():
-            lm = L.as_f32c(lm)
+        proj = []
+        for lm in lms:
             o = torch.empty(B, lm.shape[1], 2, device=dev)
             L.check(lib.smirk_project_landmarks(P(lm), P(cam), B, lm.shape[1], P(o), L.stream_ptr()))
-            out[key] = o
-        if _aux:
-            out['_aux'] = dict(pix_to_face=p2f, bary=bary, zbuf=zbuf, normals=nrm)
-        return out
+            proj.append(o)
+        aux = dict(pix_to_face=p2f, bary=bary, zbuf=zbuf, normals=nrm) if want_aux else p2f
+        return img, tv, proj, aux
+
+    def _launch_backward(self, vertices, cam, p2f, lms, g_img, g_tv, g_lms):
+        B, dev = vertices.shape[0], vertices.device
+        H = W = self.image_size
+        lib, mesh = L.lib(), self._struct()
+        d_verts, d_cam = torch.empty_like(vertices), torch.empty_like(cam)
+        g_img = None if g_img is None else L.as_f32c(g_img)
+        g_tv = None if g_tv is None else L.as_f32c(g_tv)
+        nws = lib.smirk_render_backward_workspace_bytes(mesh, B, H, W)
+        ws = self._ws.get(nws, dev)
+        P = L.ptr
+        L.check(lib.smirk_render_backward(mesh, B, H, W, P(vertices), P(cam), P(p2f, torch.int64), P(g_img, allow_none=True),
+                                          P(g_tv, allow_none=True), P(d_verts), P(d_cam), P(ws, torch.uint8), nws, L.stream_ptr()))
+        d_lms = []
+        for lm, g in zip(lms, g_lms):
+            if g is None:
+                d_lms.append(None)
+                continue
+            g = L.as_f32c(g)
+            d = torch.empty_like(lm)
+            L.check(lib.smirk_project_landmarks_backward(P(lm), P(cam), P(g), B, lm.shape[1], P(d), P(d_cam), L.stream_ptr()))
+            d_lms.append(d)
+        return d_verts, d_cam, d_lms
 
     def render(self, vertices, transformed_vertices=None):
         """Shaded image only (renderer.py:121-168).  `transformed_vertices` is recomputed from the camera inside
         smirk_render_forward, so this entry exists for signature compatibility and requires it to be None."""
         raise L.SmirkHipError("Renderer.render(vertices, transformed_vertices) is not exposed separately: call forward()")
+
+
+class _RenderFunction(torch.autograd.Function):
+    """autograd bridge: forward = smirk_render_forward (+ landmark projections) keeping pix_to_face, backward = smirk_render_backward."""
+
+    @staticmethod
+    def forward(ctx, module, n_lm, vertices, cam, *lms):
+        img, tv, proj, p2f = module._launch(vertices, cam, list(lms), False, True)
+        ctx.module = module
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(vertices, cam, p2f, *lms)
+        return (img, tv, *proj)
+
+    @staticmethod
+    def backward(ctx, g_img, g_tv, *g_lms):
+        vertices, cam, p2f, *lms = ctx.saved_tensors
+        d_verts, d_cam, d_lms = ctx.module._launch_backward(vertices, cam, p2f, lms, g_img, g_tv, g_lms)
+        return (None, None, d_verts, d_cam, *d_lms)
