@@ -282,11 +282,14 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
 //                       camera, reduce dL/dcam                                                                     -> d_verts, d_cam
 // ====================================================================================================================================
 #define FG 15
+#define BWD_LANES 16
 __global__ __launch_bounds__(256) void render_bwd_faces(MeshDev m, int B, int H, int W, const float* __restrict__ verts,
                                                         const float* __restrict__ cam, const float* __restrict__ normals,
                                                         const long long* __restrict__ p2f, const float* __restrict__ g_img,
                                                         float* __restrict__ fgrad) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = gt / BWD_LANES;                              // BWD_LANES lanes share one (image, face): balances big boxes
+    const int sub = (int)(gt % BWD_LANES);
     if (i >= (size_t)B * m.Ff) return;
     const int b = (int)(i / m.Ff), f = (int)(i % m.Ff);
     const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
@@ -314,11 +317,14 @@ __global__ __launch_bounds__(256) void render_bwd_faces(MeshDev m, int B, int H,
     const long long me = (long long)b * m.Ff + f;
     const size_t plane = (size_t)H * W;
     float g_area = 0.f;
-    for (int yi = box.z; yi <= box.w; ++yi) {
-        const float yf = pix_to_ndc(H - 1 - yi, H);
-        for (int xi = box.x; xi <= box.y; ++xi) {
+    const int bw = box.y - box.x + 1, bh = box.w - box.z + 1;
+    const int npx = (bw > 0 && bh > 0) ? bw * bh : 0;
+    {
+        for (int idx = sub; idx < npx; idx += BWD_LANES) {
+            const int yo = idx / bw, yi = box.z + yo, xi = box.x + (idx - yo * bw);
             const size_t pix = (size_t)yi * W + xi;
             if (p2f[(size_t)b * plane + pix] != me) continue;
+            const float yf = pix_to_ndc(H - 1 - yi, H);
             const float xf = pix_to_ndc(W - 1 - xi, W);
             const float e0 = edge_fn(xf, yf, x1, y1, x2, y2), e1 = edge_fn(xf, yf, x2, y2, x0, y0), e2 = edge_fn(xf, yf, x0, y0, x1, y1);
             const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
@@ -351,6 +357,13 @@ __global__ __launch_bounds__(256) void render_bwd_faces(MeshDev m, int B, int H,
             acc[4] += ge0 * (y1 - yf) + ge1 * (yf - y0);   acc[5] += ge0 * (xf - x1) + ge1 * (x0 - xf);      // v2
         }
     }
+#pragma unroll
+    for (int o = BWD_LANES / 2; o > 0; o >>= 1) {                 // fixed-order tree over the lanes of this face: deterministic
+#pragma unroll
+        for (int k = 0; k < FG; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+        g_area += __shfl_xor(g_area, o, 64);
+    }
+    if (sub != 0) return;
     // area = E(v2; v0, v1) + eps
     acc[0] += g_area * (y2 - y1); acc[1] += g_area * (x1 - x2);
     acc[2] += g_area * (y0 - y2); acc[3] += g_area * (x2 - x0);
@@ -524,7 +537,7 @@ extern "C" int smirk_render_backward(const SmirkRenderMesh* mesh, int B, int H, 
     hipLaunchKernelGGL(render_bwd_init, dim3(B), dim3(256), 0, st, B, mesh->V, verts, cam, g_transformed, d_verts, d_cam);
     if (g_img) {
         hipLaunchKernelGGL(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
-        hipLaunchKernelGGL(render_bwd_faces, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, verts, cam,
+        hipLaunchKernelGGL(render_bwd_faces, dim3((unsigned)((nf * BWD_LANES + 255) / 256)), dim3(256), 0, st, d, B, H, W, verts, cam,
                            (const float*)nrm, (const long long*)pix_to_face, g_img, fgrad);
         hipLaunchKernelGGL(render_bwd_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, (const float*)fgrad, dS);
         hipLaunchKernelGGL(render_bwd_vertices, dim3(B), dim3(256), 0, st, d, B, verts, cam, (const float*)fgrad, (const float*)dS,
