@@ -274,6 +274,30 @@ int smirk_scatter_points_mask(const int64_t* points, const int64_t* rbound, int 
 int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_t* points2, const int64_t* rbound, int B, int C,
                           int L, int H, int W, int32_t* winner_ws, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Video loop pre/post-processing — replaces the cv2 / skimage calls of demo_video.py:107-214 so that a batch
+ * of decoded frames stays in HBM from uint8 in to uint8 out.  uint8 images are HWC (cv2 layout), float images NCHW in [0,1].
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* skimage.transform.warp(img, inverse_map, output_shape=(Ho,Wo), preserve_range=True).astype(uint8) (demo_video.py:124,163,203): bilinear,
+ * constant 0 outside, float64; mats[N][6] = first two rows of the 3x3 matrix taking OUTPUT (col,row,1) to INPUT (x,y).
+ * Outputs (either nullable): out_f32_nchw = value/255 with optional R<->B swap (cvtColor + /255 + permute, demo_video.py:133-135),
+ * out_u8_hwc. */
+int smirk_warp_affine_u8(const uint8_t* src /*[N][Hs][Ws][3]*/, int N, int Hs, int Ws, const double* mats, int Ho, int Wo,
+                         int swap_rb, float* out_f32_nchw, uint8_t* out_u8_hwc, void* stream);
+/* cv2.resize(img, (Wo, Ho)) INTER_LINEAR, 8-bit fixed-point path (demo_video.py:134); same outputs as above. */
+int smirk_resize_linear_u8(const uint8_t* src, int N, int Hs, int Ws, int Ho, int Wo, int swap_rb,
+                           float* out_f32_nchw, uint8_t* out_u8_hwc, void* stream);
+/* (x*255).astype(uint8) + optional channel swap of a float NCHW panel into columns [col0, col0+W) of a uint8 HWC grid that is
+ * grid_w pixels wide = torch.cat(panels, dim=3) ... cvtColor (demo_video.py:170-172,209-214). */
+int smirk_f32_nchw_to_u8_grid(const float* src, int N, int H, int W, int swap_rb, uint8_t* grid, int grid_w, int col0, void* stream);
+/* torch.Tensor(u8).permute(2,0,1).float()/255 with optional channel swap (demo_video.py:165,169). */
+int smirk_u8_hwc_to_f32_nchw(const uint8_t* src, int N, int H, int W, int swap_rb, float* dst, void* stream);
+/* F.interpolate(x, (Ho, Wo), mode='bilinear') (align_corners=False; demo_video.py:167,207) on NC planes. */
+int smirk_interp_bilinear_f32(const float* src, int NC, int H, int W, int Ho, int Wo, float* dst, void* stream);
+/* create_mask (datasets/base_dataset.py:9-15): landmarks[N][L][stride>=2] (x, y, ...) float, truncated to int32; out[N][1][H][W] = 0 inside
+ * the closed convex hull, 1 outside.  L <= 1024. */
+int smirk_hull_mask(const float* landmarks, int N, int L, int stride, int H, int W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,5 +11,6 @@ from .renderer import Renderer  # noqa: F401
 from .smirk_encoder import SmirkEncoder  # noqa: F401
 from .smirk_generator import SmirkGenerator  # noqa: F401
 from . import masking  # noqa: F401  (drop-in for src/utils/masking.py)
+from .video import VideoPipeline  # noqa: F401  (demo_video.py's frame loop, batched + streamed)
 
-__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib", "masking"]
+__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib", "masking", "VideoPipeline"]

@@ -61,6 +61,12 @@ _SIGS = {
     "smirk_render_backward_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
     "smirk_render_backward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_project_landmarks_backward": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
+    "smirk_warp_affine_u8": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "smirk_resize_linear_u8": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "smirk_f32_nchw_to_u8_grid": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "smirk_u8_hwc_to_f32_nchw": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "smirk_interp_bilinear_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "smirk_hull_mask": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "smirk_rendered_mask": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "smirk_scatter_points_mask": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "smirk_transfer_pixels": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsmirk_hip.so")
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
-PER_FILE = {"render.hip": ["-ffp-contract=off"]}
+PER_FILE = {"render.hip": ["-ffp-contract=off"], "video.hip": ["-ffp-contract=off"]}
 
 
 def sources():

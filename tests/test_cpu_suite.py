@@ -261,3 +261,41 @@ def test_render_gradient_oracle_vs_reference_golden(sandbox, golden_dir):
         assert np.abs(t.grad.numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), k
     # the face-region sub-mesh is the only part of the mesh the image sees: gradients elsewhere come from transformed_vertices only
     assert np.count_nonzero(g["d_vertices"]) > 0
+
+
+# ---- video loop pre/post-processing: oracle/video_ref.py restates cv2 / skimage (not on disk: parity unpinned) -------
+def test_video_crop_transform_closed_form_equals_umeyama():
+    from oracle import video_ref as V
+    from smirk_amd.video import crop_transform
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        lm = rng.uniform(50, 900, (478, 3))
+        a, b = crop_transform(lm[:, :2], 1.4, 224), V.crop_transform(lm[:, :2], 1.4, 224)
+        assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(b).max())
+
+
+def test_video_oracle_known_answers():
+    import torch
+    import torch.nn.functional as F
+    from oracle import video_ref as V
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    assert np.array_equal(V.warp_u8(img, np.eye(3), (40, 56)), img)                        # identity warp
+    sh = np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1]])                                   # integer shift: out(r,c) = in(r-2, c+3), 0 outside
+    w = V.warp_u8(img, sh, (40, 56))
+    assert np.array_equal(w[2:, :53], img[:38, 3:]) and not w[:2].any() and not w[:, 53:].any()
+    half = V.warp_u8(img, np.array([[1, 0, 0.5], [0, 1, 0], [0, 0, 1]]), (40, 55))          # half-pixel: mean of two neighbours, truncated
+    assert np.array_equal(half, ((img[:, :55].astype(np.float64) + img[:, 1:56]) / 2).astype(np.uint8))
+    assert np.array_equal(V.resize_linear_u8(img, (56, 40)), img)
+    up = V.resize_linear_u8(np.full((8, 8, 3), 77, np.uint8), (21, 13))
+    assert up.shape == (13, 21, 3) and (up == 77).all()                                     # constant images stay constant
+    m = V.hull_mask(np.array([[10.9, 10.2], [30.1, 10.7], [30.5, 25.9], [10.0, 25.0], [20, 18]]), (40, 48))
+    assert m.sum() == 40 * 48 - 21 * 16 and not m[10:26, 10:31].any()                       # the closed square [10,30]x[10,25]
+    tri = V.hull_mask(np.array([[0, 0], [8, 0], [0, 8]]), (10, 10))
+    assert [int((tri[y] == 0).sum()) for y in range(10)] == [9, 8, 7, 6, 5, 4, 3, 2, 1, 0]
+    x = torch.rand(2, 3, 24, 24)
+    for hw in ((37, 53), (24, 24), (12, 100)):
+        assert np.abs(V.interp_bilinear(x.numpy(), hw) - F.interpolate(x, hw, mode="bilinear").numpy()).max() < 1e-5
+    u = np.arange(256, dtype=np.uint8)
+    rq = V.to_u8(V.from_u8(u))
+    assert (np.abs(rq.astype(int) - u) <= 1).all() and (rq == u).mean() > 0.9               # float32 /255 *255 truncation: a few values drop by 1
