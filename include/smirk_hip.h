@@ -274,6 +274,18 @@ int smirk_scatter_points_mask(const int64_t* points, const int64_t* rbound, int 
 int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_t* points2, const int64_t* rbound, int B, int C,
                           int L, int H, int W, int32_t* winner_ws, float* out, void* stream);
 
+/* One fused launch for a timm MobileNetV3 "minimal" block (smirk_encoder.py:11-21 runs them through
+ * `self.encoder(img)`): InvertedResidual = conv_pw 1x1 + bn1 + ReLU -> conv_dw 3x3 (stride 1|2, TF 'SAME') + bn2 + ReLU -> conv_pwl 1x1 + bn3
+ * (+ x when stride 1 and Cin == Cout); DepthwiseSeparable (wexp == NULL, mid == Cin) = conv_dw + bn1 + ReLU -> conv_pw + bn2 (+ x).
+ * Activations are split16 NHWC; wexp [mid][Cin] and wproj [Cout][mid] split16 rows; wdw [9][mid] fp32; s1..s3 / b1..b3 = folded eval-mode BatchNorm
+ * scale / shift.  The expanded tensors never leave the CU's LDS.  All channel counts must be multiples of 8. */
+size_t smirk_mbconv_lds_bytes(int Cin, int mid, int Cout, int stride);
+/* 1 if the fused kernel serves this block shape (Cin <= 48, Cout <= 96, LDS <= 64 KiB); otherwise use the per-layer kernels */
+int smirk_mbconv_supported(int Cin, int mid, int Cout, int stride);
+int smirk_mbconv_fused_split16(const void* x, const void* wexp, const float* s1, const float* b1, const float* wdw, const float* s2,
+                               const float* b2, const void* wproj, const float* s3, const float* b3, int residual, void* out,
+                               int B, int H, int W, int Cin, int mid, int Cout, int stride, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Video loop pre/post-processing — replaces the cv2 / skimage calls of demo_video.py:107-214 so that a batch
  * of decoded frames stays in HBM from uint8 in to uint8 out.  uint8 images are HWC (cv2 layout), float images NCHW in [0,1].

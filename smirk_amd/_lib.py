@@ -61,6 +61,9 @@ _SIGS = {
     "smirk_render_backward_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
     "smirk_render_backward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_project_landmarks_backward": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
+    "smirk_mbconv_lds_bytes": (_sz, [_i, _i, _i, _i]),
+    "smirk_mbconv_supported": (_i, [_i, _i, _i, _i]),
+    "smirk_mbconv_fused_split16": (_i, [_p] * 10 + [_i, _p] + [_i] * 7 + [_p]),
     "smirk_warp_affine_u8": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
     "smirk_resize_linear_u8": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_f32_nchw_to_u8_grid": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p]),

@@ -1,0 +1,339 @@
+// Fused MobileNetV3 block for gfx950 — one launch per InvertedResidual / DepthwiseSeparable block of the timm "minimal" backbones
+// (reference call site smirk_encoder.py:11-21 `self.encoder(img)[-1]`):
+//
+//      x --1x1 expand + BN + ReLU--> E --3x3 depthwise (stride 1|2, TF-SAME) + BN + ReLU--> D --1x1 project + BN (+x)--> out
+//
+// The unfused path writes E and D to HBM and reads them back (E is 3-6x wider than x: 4E + x + out bytes per block).  Here a workgroup
+// owns an 8x8 (stride 1) or 4x8 (stride 2) output tile, stages the matching input halo tile of x in LDS ONCE, and walks the expanded
+// channels in chunks of 32:
+//      phase 1   E_c[halo px][32]  = relu(bn1(X . Wexp_c))      split-fp16 x3 MFMA (v_mfma_f32_32x32x16_f16), A from LDS, B from L1/L2;
+//                                     rows outside the image are forced to 0 (the depthwise conv zero-pads E, not x)      -> LDS fp32
+//      phase 2   D_c[out px][32]   = relu(bn2(dw3x3(E_c)))       fp32 VALU, lane = channel                                  -> LDS split16
+//      phase 3   P[out px][Cout]  += D_c . Wproj_c               MFMA, accumulators stay in registers across the chunks
+// and finally out = bn3(P) (+ x) re-split to the split16 activation layout.  HBM traffic per block: the input tile with its halo
+// ((10/8)^2 = 1.56x at stride 1, 1.13x at stride 2) + the output — 5-8x less than the unfused sequence at 112^2..28^2.
+// Bound: HBM at 112^2/56^2 (then latency: 2 barriers per 32-channel chunk); arithmetic identical in kind to the unfused kernels
+// (f16x3 products, fp32 accumulation, fp32 depthwise), E is kept in fp32 instead of being rounded to split16 in between.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct MBArgs {
+    const char* x;          // split16 NHWC, Cin*4 bytes per pixel
+    const char* wexp;       // [mid][Cin] split16 rows (Cin*4 bytes), NULL for a DepthwiseSeparable block (mid == Cin, E = x)
+    const float *s1, *b1;   // [mid]
+    const float* wdw;       // [9][mid]
+    const float *s2, *b2;   // [mid]
+    const char* wproj;      // [Cout][mid] split16 rows
+    const float *s3, *b3;   // [Cout]
+    char* out;              // split16 NHWC [B][Ho][Wo][Cout]
+    int B, H, W, Cin, mid, Cout, Ho, Wo, pt, pl, residual, cinp, coutp, tiles_x, tiles_y, es_floats;
+};
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, which would expose the latency of the
+// weight-fragment prefetches that are deliberately left in flight across the phases
+__device__ __forceinline__ void mb_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ float mb_join(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
+
+// KS = Cin rounded up to 16, in 16-k MFMA steps (1..3: the fused path serves the blocks with Cin <= 48, i.e. everything down to 14x14)
+template <int S, bool EXP, int KS>
+__global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
+    constexpr int THO = (S == 1) ? 8 : 4, TWO = 8;
+    constexpr int HI = (THO - 1) * S + 3, WI = (TWO - 1) * S + 3, NH = HI * WI, MH = (NH + 31) / 32 * 32, MO = THO * TWO;
+    constexpr int ES = 36, DSB = 144;                     // Es row stride (floats, 16-B aligned rows), Ds row stride (bytes: 32 ch x 4 B + 16)
+    constexpr int P3 = (S == 1) ? 2 : 1;                  // project tiles per wave: (MO/32) x (Cout<=96)/32 = 6 | 3 tiles over 4 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int strideX = a.cinp * 4 + 16;                  // odd multiple of 16 B: the 16 rows of a ds_read_b128 group hit 16 distinct slots
+    const int nchunks = (a.mid + 31) / 32, midp = nchunks * 32;
+    char* Xs = smem;
+    float* Es = (float*)(Xs + MH * strideX);
+    char* Ds = (char*)(Es + a.es_floats);
+    float* Wd = (float*)(Ds + MO * DSB);                  // [13][midp]: 9 depthwise taps, s2, b2, s1, b1 (zero beyond mid)
+    unsigned char* ok = (unsigned char*)(Wd + 13 * midp);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, hb = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int oy0 = ty * THO, ox0 = tx * TWO, iy0 = oy0 * S - a.pt, ix0 = ox0 * S - a.pl;
+    const size_t xrow = (size_t)a.Cin * 4;
+    const int gmax = a.Cin / 8;
+    const int ntn = a.coutp / 32, ntiles = (MO / 32) * ntn;
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    half8 we[KS][2];                                      // this lane's expand-weight fragments of the current chunk (column = 32c + fr)
+    auto load_we = [&](int c) {
+        const int ch = 32 * c + fr;
+        const char* wrow = a.wexp + (size_t)(ch < a.mid ? ch : 0) * xrow;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int g = 2 * s + hb;
+            const bool v = ch < a.mid && g < gmax;
+            we[s][0] = v ? *(const half8*)(wrow + g * 32) : hz;
+            we[s][1] = v ? *(const half8*)(wrow + g * 32 + 16) : hz;
+        }
+    };
+    if constexpr (EXP) load_we(0);
+
+    // ---- phase 0: halo tile of x -> LDS (zeros outside the image / beyond Cin / beyond NH); depthwise + BN constants -> LDS -----------
+    {
+        const int P = a.cinp / 4, Preal = a.Cin / 4;
+        const char* xb = a.x + (size_t)b * a.H * a.W * xrow;
+        for (int idx = tid; idx < MH * P; idx += 256) {
+            const int row = idx / P, pc = idx - row * P;
+            const int iy = iy0 + row / WI, ix = ix0 + row % WI;
+            const bool in = row < NH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in && pc < Preal) v = *(const f32x4*)(xb + ((size_t)iy * a.W + ix) * xrow + pc * 16);
+            *(f32x4*)(Xs + row * strideX + pc * 16) = v;
+            if (pc == 0) ok[row] = in ? 1 : 0;
+        }
+        for (int idx = tid; idx < 13 * midp; idx += 256) {
+            const int k = idx / midp, ch = idx - k * midp;
+            float v = 0.f;
+            if (ch < a.mid) {
+                if (k < 9) v = a.wdw[k * a.mid + ch];
+                else if (k == 9) v = a.s2[ch];
+                else if (k == 10) v = a.b2[ch];
+                else if (EXP) v = (k == 11) ? a.s1[ch] : a.b1[ch];
+            }
+            Wd[idx] = v;
+        }
+    }
+    mb_barrier();
+
+    // validity of the 16 accumulator rows this lane owns in each of its (at most 2) phase-1 tiles: bit r of okm[i]
+    unsigned okm[2] = {0u, 0u};
+    if constexpr (EXP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave + 4 * i;
+            if (t < MH / 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) okm[i] |= (unsigned)ok[t * 32 + mfma32_row(r, lane)] << r;
+            }
+        }
+    }
+
+    f32x16 pacc[P3][2];
+#pragma unroll
+    for (int q = 0; q < P3; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[q][h][r] = 0.f;
+
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- phase 1 ----------------------------------------------------------------------------------------------------------
+        if constexpr (EXP) {
+            const float s1 = Wd[11 * midp + 32 * c + fr], b1 = Wd[12 * midp + 32 * c + fr];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int t = wave + 4 * ti;
+                if (t >= MH / 32) break;
+                f32x16 e0, e1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
+                const char* arow = Xs + (t * 32 + fr) * strideX;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int g = 2 * s + hb;
+                    const half8 ah = *(const half8*)(arow + g * 32), al = *(const half8*)(arow + g * 32 + 16);
+                    e0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, we[s][0], e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, we[s][1], e1, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, we[s][0], e1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = t * 32 + mfma32_row(r, lane);
+                    if (row < NH) {
+                        const float v = fmaxf((e0[r] + e1[r] * (1.0f / 2048.0f)) * s1 + b1, 0.f);
+                        Es[row * ES + fr] = ((okm[ti] >> r) & 1u) ? v : 0.f;     // the depthwise conv zero-pads E (not x)
+                    }
+                }
+            }
+            if (c + 1 < nchunks) load_we(c + 1);          // same registers: the fetch runs under phases 2-3
+        } else {                                          // DepthwiseSeparable: the depthwise conv reads x itself
+            for (int idx = tid; idx < NH * 4; idx += 256) {
+                const int row = idx >> 2, g = (idx & 3) + 4 * c;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+                if (g < gmax) {
+                    const half8 hi = *(const half8*)(Xs + row * strideX + g * 32), lo = *(const half8*)(Xs + row * strideX + g * 32 + 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v0[k] = mb_join(hi[k], lo[k]); v1[k] = mb_join(hi[4 + k], lo[4 + k]); }
+                }
+                *(f32x4*)(Es + row * ES + (idx & 3) * 8) = v0;
+                *(f32x4*)(Es + row * ES + (idx & 3) * 8 + 4) = v1;
+            }
+        }
+        mb_barrier();
+        // ---- phase 2: depthwise 3x3 + BN + ReLU; a lane owns 4 consecutive channels of a pixel, 32 pixels per pass ------------------------
+        {
+            const int c4 = tid & 7, cb = 32 * c + c4 * 4;
+            f32x4 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *(const f32x4*)(Wd + k * midp + cb);
+            const f32x4 s2 = *(const f32x4*)(Wd + 9 * midp + cb), b2 = *(const f32x4*)(Wd + 10 * midp + cb);
+#pragma unroll
+            for (int q = 0; q < MO / 32; ++q) {
+                const int p = (tid >> 3) + 32 * q, oy = p / TWO, ox = p % TWO;
+                const float* e = Es + ((oy * S) * WI + ox * S) * ES + c4 * 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 v = *(const f32x4*)(e + (ky * WI + kx) * ES);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] = fmaf(v[k], w[ky * 3 + kx][k], acc[k]);
+                    }
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                half4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = fmaxf(acc[k] * s2[k] + b2[k], 0.f);
+                    const _Float16 h = (_Float16)v;
+                    hi[k] = h;
+                    lo[k] = (_Float16)((v - (float)h) * 2048.0f);
+                }
+                char* d = Ds + p * DSB + (c4 >> 1) * 32 + (c4 & 1) * 8;
+                *(half4*)d = hi;
+                *(half4*)(d + 16) = lo;
+            }
+        }
+        mb_barrier();
+        // ---- phase 3: project, accumulate over chunks --------------------------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < P3; ++q) {
+            const int id = wave + 4 * q;
+            if (id < ntiles) {
+                const int mt = id / ntn, nt = id - mt * ntn, co = nt * 32 + fr;
+                const char* arow = Ds + (mt * 32 + fr) * DSB;
+                const char* wrow = a.wproj + (size_t)(co < a.Cout ? co : 0) * a.mid * 4;
+                half8 wp[2][2];                          // (the other resident workgroups of the CU cover this fetch)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int kg = 4 * c + 2 * s + hb;
+                    const bool v = co < a.Cout && kg * 8 < a.mid;
+                    wp[s][0] = v ? *(const half8*)(wrow + kg * 32) : hz;
+                    wp[s][1] = v ? *(const half8*)(wrow + kg * 32 + 16) : hz;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int g = 2 * s + hb;
+                    const half8 ah = *(const half8*)(arow + g * 32), al = *(const half8*)(arow + g * 32 + 16);
+                    pacc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wp[s][0], pacc[q][0], 0, 0, 0);
+                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wp[s][1], pacc[q][1], 0, 0, 0);
+                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wp[s][0], pacc[q][1], 0, 0, 0);
+                }
+            }
+        }
+        // no barrier: the next chunk's phase 1 writes Es only (last read in phase 2, fenced above); its phase 2 rewrites Ds after the
+        // barrier that follows phase 1, which every wave reaches only once its phase 3 is done.
+    }
+    // ---- epilogue: bn3 -> LDS (re-using Es) -> (+ residual) -> split16 stores ---------------------------------------------------------
+    float* Os = Es;
+#pragma unroll
+    for (int q = 0; q < P3; ++q) {
+        const int id = wave + 4 * q;
+        if (id < ntiles) {
+            const int mt = id / ntn, nt = id - mt * ntn, co = nt * 32 + fr;
+            const float s3 = co < a.Cout ? a.s3[co] : 0.f, b3 = co < a.Cout ? a.b3[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + mfma32_row(r, lane);
+                Os[row * a.coutp + co] = (pacc[q][0][r] + pacc[q][1][r] * (1.0f / 2048.0f)) * s3 + b3;
+            }
+        }
+    }
+    mb_barrier();
+    {
+        const int G = a.Cout / 8;
+        char* ob = a.out + (size_t)b * a.Ho * a.Wo * a.Cout * 4;
+        for (int idx = tid; idx < MO * G; idx += 256) {
+            const int p = idx / G, g8 = idx - p * G;
+            const int oy = oy0 + p / TWO, ox = ox0 + p % TWO;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = Os[p * a.coutp + g8 * 8 + k];
+            if (a.residual) {                             // stride 1, Cin == Cout: x at the same pixel = halo row (y + pt, x + pl)
+                const char* xr = Xs + ((p / TWO + a.pt) * WI + (p % TWO) + a.pl) * strideX + g8 * 32;
+                const half8 hi = *(const half8*)xr, lo = *(const half8*)(xr + 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += mb_join(hi[k], lo[k]);
+            }
+            half8 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const _Float16 h = (_Float16)v[k];
+                hi[k] = h;
+                lo[k] = (_Float16)((v[k] - (float)h) * 2048.0f);
+            }
+            char* o = ob + ((size_t)oy * a.Wo + ox) * a.Cout * 4 + g8 * 32;
+            *(half8*)o = hi;
+            *(half8*)(o + 16) = lo;
+        }
+    }
+}
+
+static int mb_same_pad_lead(int n, int s) {
+    const int o = (n + s - 1) / s;
+    int t = (o - 1) * s + 3 - n;
+    if (t < 0) t = 0;
+    return t / 2;
+}
+
+extern "C" size_t smirk_mbconv_lds_bytes(int Cin, int mid, int Cout, int stride) {
+    const int cinp = (Cin + 15) / 16 * 16, coutp = (Cout + 31) / 32 * 32, midp = (mid + 31) / 32 * 32;
+    const int NH = stride == 1 ? 100 : 153, MH = (NH + 31) / 32 * 32, MO = stride == 1 ? 64 : 32;
+    const size_t es = (size_t)((NH * 36 > MO * coutp) ? NH * 36 : MO * coutp);
+    return (size_t)MH * (cinp * 4 + 16) + es * 4 + (size_t)MO * 144 + (size_t)13 * midp * 4 + MH;
+}
+
+/* 1 if smirk_mbconv_fused_split16 serves this block shape (the caller keeps the unfused kernel sequence otherwise) */
+extern "C" int smirk_mbconv_supported(int Cin, int mid, int Cout, int stride) {
+    if ((stride != 1 && stride != 2) || Cin % 8 || mid % 8 || Cout % 8 || Cin <= 0 || mid <= 0 || Cout <= 0) return 0;
+    return Cin <= 48 && Cout <= 96 && smirk_mbconv_lds_bytes(Cin, mid, Cout, stride) <= 64 * 1024;
+}
+
+template <int S, bool EXP>
+static void mb_launch(const MBArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    const int ks = a.cinp / 16;
+    if (ks == 1) hipLaunchKernelGGL((mbconv_fused_kernel<S, EXP, 1>), grid, dim3(256), lds, st, a);
+    else if (ks == 2) hipLaunchKernelGGL((mbconv_fused_kernel<S, EXP, 2>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mbconv_fused_kernel<S, EXP, 3>), grid, dim3(256), lds, st, a);
+}
+
+extern "C" int smirk_mbconv_fused_split16(const void* x, const void* wexp, const float* s1, const float* b1, const float* wdw,
+                                          const float* s2, const float* b2, const void* wproj, const float* s3, const float* b3,
+                                          int residual, void* out, int B, int H, int W, int Cin, int mid, int Cout, int stride,
+                                          void* stream) {
+    if (!x || !wdw || !s2 || !b2 || !wproj || !s3 || !b3 || !out || B <= 0 || H <= 0 || W <= 0) return SMIRK_ERR_BAD_ARG;
+    if (wexp && (!s1 || !b1)) return SMIRK_ERR_BAD_ARG;
+    if (!wexp && mid != Cin) return SMIRK_ERR_BAD_ARG;
+    if (residual && (stride != 1 || Cin != Cout)) return SMIRK_ERR_BAD_ARG;
+    if (!smirk_mbconv_supported(Cin, mid, Cout, stride)) return SMIRK_ERR_UNSUPPORTED;
+    MBArgs a;
+    a.x = (const char*)x; a.wexp = (const char*)wexp; a.s1 = s1; a.b1 = b1; a.wdw = wdw; a.s2 = s2; a.b2 = b2;
+    a.wproj = (const char*)wproj; a.s3 = s3; a.b3 = b3; a.out = (char*)out;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.Cout = Cout; a.residual = residual;
+    a.Ho = (H + stride - 1) / stride; a.Wo = (W + stride - 1) / stride;
+    a.pt = stride == 1 ? 1 : mb_same_pad_lead(H, stride); a.pl = stride == 1 ? 1 : mb_same_pad_lead(W, stride);
+    a.cinp = (Cin + 15) / 16 * 16; a.coutp = (Cout + 31) / 32 * 32;
+    const int THO = stride == 1 ? 8 : 4, NH = stride == 1 ? 100 : 153, MO = stride == 1 ? 64 : 32;
+    a.tiles_x = (a.Wo + 7) / 8; a.tiles_y = (a.Ho + THO - 1) / THO;
+    a.es_floats = (NH * 36 > MO * a.coutp) ? NH * 36 : MO * a.coutp;
+    const size_t lds = smirk_mbconv_lds_bytes(Cin, mid, Cout, stride);
+    const dim3 grid((unsigned)((size_t)B * a.tiles_x * a.tiles_y));
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1) { if (wexp) mb_launch<1, true>(a, grid, lds, st); else mb_launch<1, false>(a, grid, lds, st); }
+    else { if (wexp) mb_launch<2, true>(a, grid, lds, st); else mb_launch<2, false>(a, grid, lds, st); }
+    return smirk_launch_status();
+}

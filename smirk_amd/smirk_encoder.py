@@ -156,6 +156,27 @@ class MobileNetV3Features(nn.Module):
         L.check((lib.smirk_dwconv3x3_split16 if self._split else lib.smirk_dwconv3x3)(P(x), P(w), P(sc), P(sh), P(out), B, H, W, C, stride, 1, st))
         return out
 
+    @staticmethod
+    def _fusable(lib, cin, pk, blk):
+        if blk.kind == "ds" and not os.environ.get("SMIRK_MBCONV_FUSE_DS"):
+            return False        # measured: no expanded tensor to keep on chip, the two streaming kernels are as fast (s1) or faster (s2)
+        return bool(lib.smirk_mbconv_supported(cin, pk["dw"][0].shape[1], pk["pw" if blk.kind == "ds" else "pwl"][0].shape[0], blk.stride))
+
+    def _fused_block(self, lib, st, x, pk, blk):
+        """whole DS / IR block in one launch (csrc/mbconv.hip): the expanded activations stay in LDS"""
+        B, H, W, C = x.shape
+        P, N = L.ptr, (lambda t: L.ptr(t, allow_none=True))
+        if blk.kind == "ds":
+            (wd, s2, b2), (wp, s3, b3) = pk["dw"], pk["pw"]
+            we = s1 = b1 = None
+        else:
+            (we, s1, b1), (wd, s2, b2), (wp, s3, b3) = pk["pw"], pk["dw"], pk["pwl"]
+        mid, cout, s = wd.shape[1], wp.shape[0], blk.stride
+        out = torch.empty(B, (H + s - 1) // s, (W + s - 1) // s, cout, device=x.device)
+        L.check(lib.smirk_mbconv_fused_split16(P(x), N(we), N(s1), N(b1), P(wd), P(s2), P(b2), P(wp), P(s3), P(b3), int(bool(blk.skip)),
+                                               P(out), B, H, W, C, mid, cout, s, st))
+        return out
+
     def forward(self, img):
         """img [B,3,H,W] NCHW in [0,1] -> last feature map NHWC [B,H/32,W/32,C] (fp32, or split16 storage when PRECISION == "f16x3":
         see `features_f32`)."""
@@ -167,10 +188,13 @@ class MobileNetV3Features(nn.Module):
         w, sc, sh = P["stem"]
         x = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 16, device=img.device)
         L.check((lib.smirk_stem_conv_s2_split16 if self._split else lib.smirk_stem_conv_s2)(L.ptr(img), L.ptr(w), L.ptr(sc), L.ptr(sh), L.ptr(x), B, H, W, 16, st))
+        fused = self._split and not os.environ.get("SMIRK_DISABLE_MBCONV_FUSED")
         for si, stg in enumerate(self.blocks):
             for bi, blk in enumerate(stg):
                 pk = P[(si, bi)]
-                if blk.kind == "ds":
+                if fused and blk.kind in ("ds", "ir") and self._fusable(lib, x.shape[3], pk, blk):
+                    x = self._fused_block(lib, st, x, pk, blk)
+                elif blk.kind == "ds":
                     y = self._depthwise(lib, st, x, pk["dw"], blk.stride)
                     x = self._pointwise(lib, st, y, pk["pw"], relu=False, residual=x if blk.skip else None)
                 elif blk.kind == "ir":

@@ -84,3 +84,22 @@ def test_overlapped_pipeline_equals_serial(enc, sandbox):
     for a, b in zip(serial, got[1:]):
         for key in ("vertices", "rendered_img", "reconstructed_img", "cam", "landmarks_fan"):
             assert torch.equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (200, 184), (72, 104)])
+def test_fused_mbconv_blocks_match_unfused_sequence(enc, hw):
+    """csrc/mbconv.hip (one launch per block, expanded activations in LDS) vs the pointwise / depthwise / pointwise kernel sequence,
+    incl. feature maps that are odd-sized or not a multiple of the 8x8 tile (TF 'SAME' padding on both parities)."""
+    from smirk_amd.smirk_encoder import features_f32
+    m, _ = enc
+    img = A.synth_images(3, seed=9)[:, :, :hw[0], :hw[1]].contiguous().cuda()
+    for name in ("pose_encoder", "shape_encoder"):
+        bb = getattr(m, name).encoder
+        os.environ["SMIRK_DISABLE_MBCONV_FUSED"] = "1"
+        try:
+            ref = features_f32(bb, bb(img)).cpu()
+        finally:
+            del os.environ["SMIRK_DISABLE_MBCONV_FUSED"]
+        got = features_f32(bb, bb(img)).cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
