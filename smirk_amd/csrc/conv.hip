@@ -410,7 +410,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                 for (int r = 0; r < 16; ++r)
                     ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] =
                         SPLIT ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] * (1.0f / 2048.0f) : acc[0][i][j][r];
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // per-wave buffer: no workgroup barrier, and no vmcnt drain (a
+                                                                  // __syncthreads here would wait for the previous pass's output stores)
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int item = it * 64 + lane, row = item / GPR, g = item % GPR;
@@ -465,7 +466,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                     }
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else {
 #pragma unroll

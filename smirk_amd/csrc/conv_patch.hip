@@ -26,6 +26,22 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __device__ __attribute__((aligned(16))) float g_zero16_patch[4] = {0.f, 0.f, 0.f, 0.f};
 #define g_zero16 g_zero16_patch
 
+// Workgroup barrier / wave-local fence that wait for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for the output
+// stores just issued (write latency, 2-3 times per patch) and for the next patch's operand DMA — none of which the epilogue depends on.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// branch-free pointer select (hipcc turns `c ? p : q` feeding a DMA into exec-masked branches around each load: measured 3 branches per
+// halo row, ~400 scalar/vector instructions per patch and wave before this)
+__device__ __forceinline__ const float* psel_p(bool c, const float* p, const float* q) {
+    const unsigned long long m = 0ull - (unsigned long long)c;
+    return (const float*)(((unsigned long long)p & m) | ((unsigned long long)q & ~m));
+}
+
 struct PatchArgs {
     const float *in0, *in1, *w, *scale, *shift;
     float* out;
@@ -115,7 +131,8 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
                 const int pix = pixbase + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
                 const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
                 const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (cb + piece * 4) < cs;
-                const float* g = ok ? src + ((size_t)(b * a.H + iy) * a.W + ix) * cs + cb + piece * 4 : g_zero16;
+                const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);     // keep the unselected address in range
+                const float* g = psel_p(ok, src + ((size_t)(b * a.H + cy) * a.W + cx) * cs + cb + piece * 4, g_zero16);
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + pixbase * 32), 16, 0, 0);
             }
         }
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
         }
         if (cc == a.nchunk - 1) {
             // ---- epilogue: this stage's LDS is dead now (next DMA went to the other stage): use it as per-wave transpose buffers
-            __syncthreads();
+            lds_barrier();
             float* ebuf = St + st * PSTAGE + wave * 32 * EPI_LD;
             constexpr int GPR = COUT / 8, ITEMS = 32 * GPR / 64;
 #pragma unroll
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
-                __syncthreads();
+                wave_lds_fence();          // per-wave transpose buffer: LDS ops of one wave execute in order
 #pragma unroll
                 for (int it = 0; it < ITEMS; ++it) {
                     const int e = it * 64 + lane, row = e / GPR, g = e % GPR;
@@ -248,11 +265,11 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
                         *(half8*)(o + 4) = lo;
                     }
                 }
-                __syncthreads();
+                wave_lds_fence();          // per-wave transpose buffer: LDS ops of one wave execute in order
             }
         }
         if (NST == 1) {
-            __syncthreads();                                     // everyone is done with the only stage (compute or epilogue)
+            lds_barrier();                                        // everyone is done with the only stage (compute or epilogue)
             if (nxt < nitem) issue_item(nxt, 0);
         } else {
             st ^= 1;
@@ -309,7 +326,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
                 const int pix = pixbase + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
                 const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
                 const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                const float* g = ok ? src + ((size_t)(b * a.H + iy) * a.W + ix) * cs + cb + piece * 4 : g_zero16;
+                const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);     // keep the unselected address in range
+                const float* g = psel_p(ok, src + ((size_t)(b * a.H + cy) * a.W + cx) * cs + cb + piece * 4, g_zero16);
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + pixbase * 32), 16, 0, 0);
             }
         }
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         if (cc == a.nchunk - 1) {
             int b, oy0, ox0;
             patch_origin(p, b, oy0, ox0);
-            __syncthreads();                                     // the current input stage is dead: per-wave transpose buffers
+            lds_barrier();                                        // the current input stage is dead: per-wave transpose buffers
             float* ebuf = St + (chunk_no & 1) * PSTAGE + wave * 32 * EPI_LD;
             constexpr int GPR = COUT / 8, ITEMS = 32 * GPR / 64;
 #pragma unroll
@@ -397,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc0[j][i][r] + acc1[j][i][r] * (1.0f / 2048.0f);
-                __syncthreads();
+                wave_lds_fence();          // per-wave transpose buffer: LDS ops of one wave execute in order
 #pragma unroll
                 for (int e0 = 0; e0 < ITEMS; ++e0) {
                     const int e = e0 * 64 + lane, row = e / GPR, g = e % GPR;
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
                     *(half8*)o = hi;
                     *(half8*)(o + 4) = lo;
                 }
-                __syncthreads();
+                wave_lds_fence();          // per-wave transpose buffer: LDS ops of one wave execute in order
             }
         }
         ++chunk_no;
