@@ -286,7 +286,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     };
 
     // one operand-DMA instruction of the next chunk (slot q of PA + PB), pointer bumps after the last one
-    auto issue_slot = [&](int st, int q) {
+    [[maybe_unused]] auto issue_slot = [&](int st, int q) {
         float* As = smem + st * STAGE;
         float* Bs = As + BM * 32;
         const bool kv = (KWALK == KW_FAST_KT) ? (kleft > 0) : true;
