@@ -509,8 +509,22 @@ template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
 __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN == 128 * 128 && WGM * WGN == 8) ? 4 : 2) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
     const int ntn = (a.N + BN - 1) / BN;
-    const int logical = xcd_logical(blockIdx.x, gridDim.x);
-    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, (logical / ntn) * BM, (logical % ntn) * BN);
+    int mt, nt;
+    if (a.ablate == 2) {
+        // weight-panel-per-XCD order (ntn in {1,2,4,8}): XCD x keeps ONE BN-column weight panel (BN x K x 4 B, e.g. 2.4 MB for 512x3x3)
+        // in its 4 MB L2 for the whole launch and walks a contiguous range of M tiles; with the n-fastest order an XCD's resident
+        // workgroups touch every panel at once (9.4 MB for Cout = 512) and each of them streams its operands from the Infinity Cache
+        const int ntm = (a.M + BM - 1) / BM, groups = 8 / ntn;
+        const int x = blockIdx.x & 7, t = blockIdx.x >> 3, g = x / ntn;
+        const int m0 = (g * ntm) / groups, m1 = ((g + 1) * ntm) / groups;
+        if (t >= m1 - m0) return;
+        nt = x % ntn;
+        mt = m0 + t;
+    } else {
+        const int logical = xcd_logical(blockIdx.x, gridDim.x);
+        mt = logical / ntn; nt = logical % ntn;
+    }
+    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, mt * BM, nt * BN);
 }
 
 // Deep-ring variant: NS operand stages in dynamic LDS, one workgroup per CU (see conv_tile).
@@ -564,6 +578,13 @@ static void launch_igemm_kw(ConvArgs a, hipStream_t st, bool balance_tail) {
                 return;
             }
         }
+    }
+    static const bool panel_order = getenv("SMIRK_IGEMM_PANEL_ORDER") != nullptr;
+    if (panel_order && (ntn == 1 || ntn == 2 || ntn == 4 || ntn == 8) && ntm >= 64) {
+        const int groups = 8 / ntn;
+        a.ablate = 2;
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(8 * ((ntm + groups - 1) / groups)), dim3(64 * WGM * WGN), 0, st, a);
+        return;
     }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
 }
