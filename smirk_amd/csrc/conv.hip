@@ -94,7 +94,11 @@ __device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 +
 //               (tap, source) SEGMENT and advance by 128 bytes per chunk
 //   KW_FAST_KT  1x1 convolutions with any C % 4 == 0 (the encoders' pointwise layers): one segment per source whose last chunk is
 //               partial — lanes whose 16-byte piece lies beyond the segment read the zero page
-enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2 };
+//   KW_CMAJOR   3x3 with every source C % 32 == 0, walked channel-chunk-major with the 9 taps of a chunk back to back: the taps re-read
+//               (shifted) the same input pixels, so in this order the re-reads are L2 hits; tap-major order puts a whole pass over the
+//               channels (> the 4 MB L2 of an XCD) between them and every tap's rows come back from the Infinity Cache, whose ~7 TB/s
+//               (tools/igemm_micro.py) — not the matrix pipe — then sets the pace
+enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2, KW_CMAJOR = 3 };
 
 // one BM x BN output tile at (m0, n0); `smem` holds 2 pipeline stages of (BM + BN) x 32 dwords
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, int NS = 2>
@@ -106,7 +110,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     constexpr int STAGE = (BM + BN) * 32;                       // dwords per pipeline stage
     constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (vector epilogue)
     static_assert(NW * 32 * EPI_LD <= NS * STAGE, "epilogue buffer must fit in the operand LDS");
-    static_assert(NS == 2 || KWALK != KW_GENERIC, "the deep ring serves the channel-aligned K walks");
+    static_assert(NS == 2 || KWALK == KW_FAST || KWALK == KW_FAST_KT, "the deep ring serves the channel-aligned tap-major K walks");
     static_assert(BM % RP == 0 && BN % RP == 0, "tile must be a whole number of DMA passes");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,6 +165,47 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             const float* g = psel(kval, a.w + wrow[p] + k, g_zero16);
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
         }
+    };
+
+    // ---- KW_CMAJOR: per staged row, the (reflected / clamped) pixel-row and column offsets of the three ky / kx, and a 9-bit tap validity mask
+    int rowoff[PA][3], coloff[PA][3];
+    unsigned vmask[PA];
+    if constexpr (KWALK == KW_CMAJOR) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int iy0 = pyx[p] >> 16, ix0 = (int)(short)(pyx[p] & 0xffff);
+            unsigned oky = 0, okx = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int iy = iy0 + k, ix = ix0 + k;
+                if (d.pad_mode == SMIRK_PAD_REFLECT) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); oky |= 1u << k; okx |= 1u << k; }
+                else { oky |= (unsigned)(iy >= 0 && iy < d.H) << k; okx |= (unsigned)(ix >= 0 && ix < d.W) << k; }
+                rowoff[p][k] = boff[p] + min(max(iy, 0), d.H - 1) * d.W;
+                coloff[p][k] = min(max(ix, 0), d.W - 1);
+            }
+            vmask[p] = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) vmask[p] |= (((oky >> (t / 3)) & (okx >> (t % 3))) & 1u) << t;
+        }
+    }
+    auto issue_cmajor = [&](int cc, int tap, int st) {           // tap is a compile-time constant at every call site
+        float* As = smem + st * STAGE;
+        float* Bs = As + BM * 32;
+        const int c0 = cc * CV_BK;
+        const bool s1 = c0 >= d.C0;
+        const float* src = s1 ? a.in1 : a.in0;
+        const int cs = s1 ? d.C1 : d.C0, cb = (s1 ? c0 - d.C0 : c0) + col4 * 4;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const float* g = src + ((size_t)(rowoff[p][ky] + coloff[p][kx]) * cs + cb);
+            g = psel((vmask[p] >> tap) & 1u, g, g_zero16);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + RP * p) * 32), 16, 0, 0);
+        }
+        const float* wb = a.w + (tap * a.Cin + c0 + col4 * 4);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wb + wrow[p]), (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
     };
 
     // ---- KW_FAST*: segment state ------------------------------------------------------------------------------------------------------
@@ -310,6 +355,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             if (ch + 1 < nchunk) issue_generic((ch + 1) * CV_BK, (ch + 1) & 1);
             compute(smem + (ch & 1) * STAGE, smem + (ch & 1) * STAGE + BM * 32);
         }
+    } else if constexpr (KWALK == KW_CMAJOR) {
+        const int ncc = (d.C0 + d.C1) / CV_BK;
+        issue_cmajor(0, 0, 0);
+        int par = 0;
+        for (int cc = 0; cc < ncc; ++cc) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                chunk_ready();
+                const float* As = smem + par * STAGE;
+                par ^= 1;
+                if (tap < 8) issue_cmajor(cc, tap + 1, par);
+                else if (cc + 1 < ncc) issue_cmajor(cc + 1, 0, par);
+                compute(As, As + BM * 32);
+            }
+        }
     } else if constexpr (NS > 2) {
         // Deep ring (one workgroup per CU, NS stages): NS-1 chunks of operands are in flight while one is being consumed.  The L2->LDS
         // stream is latency-bound (bytes in flight / ~1 us), so with one chunk in flight per workgroup the operand delivery, not the
@@ -325,6 +385,27 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
+        if (a.ablate == 5 && NS == 4 && (nloop & 1) == 0) {
+            // "BK = 64" mode: the 4 stages form two double-stages; one barrier per TWO 32-k chunks (48 MFMAs per wave between barriers), so
+            // the per-barrier bubble (barrier skew + first fragment reads + DMA issue) is paid half as often
+            open_segment(); issue_fast(0);
+            if (seg_left == 0) open_segment();
+            issue_fast(1);
+            for (int ch = 0; ch < nloop; ch += 2) {
+                const bool more = ch + 2 < nloop;
+                if (more && seg_left == 0) open_segment();
+                chunk_ready();
+                const float* A0 = smem + (ch % NS) * STAGE;
+                const float* A1 = smem + ((ch + 1) % NS) * STAGE;
+                if (more) {
+                    issue_fast((ch + 2) % NS);
+                    if (seg_left == 0) open_segment();
+                    issue_fast((ch + 3) % NS);
+                }
+                compute(A0, A0 + BM * 32);
+                compute(A1, A1 + BM * 32);
+            }
+        } else {
         int issued = 0;
         for (; issued < NS - 1 && issued < nloop; ++issued) {
             if (seg_left == 0) open_segment();
@@ -342,6 +423,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             chunk_ready();
             const float* As = smem + (ch % NS) * STAGE;
             compute(As, As + BM * 32);
+        }
         }
     } else {
         const int nloop = d.KH * d.KW * ((d.C0 + CV_BK - 1) / CV_BK + (d.C1 + CV_BK - 1) / CV_BK);
@@ -604,6 +686,16 @@ static void launch_igemm_deep(const ConvArgs& a, hipStream_t st) {
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
 static void launch_igemm(const ConvArgs& a, hipStream_t st, bool balance_tail = false) {
     const SmirkConvDesc& d = a.d;
+    // measured (B=128, same box, tap-major -> channel-major): 56x56 64->128 0.221 -> 0.201 ms, 128->128 0.367 -> 0.344, 256->128 0.725 -> 0.655;
+    // 28x28 128->256 0.203 -> 0.184, 256->256 0.357 -> 0.336, 512->256 0.680 -> 0.652; 14x14 layers unchanged; 112x112 64->64 (128x64 tile) 0.51 -> 0.54
+    static const char* cm_env = getenv("SMIRK_IGEMM_CMAJOR");    // "0" forces tap-major, "1" forces channel-major everywhere it applies
+    const bool cmajor = cm_env ? (cm_env[0] != '0') : (BN == 128 && d.Ho * d.Wo >= 400);
+    if constexpr (SPLIT && WGM * WGN == 4) {
+        if (cmajor && d.KH == 3 && d.KW == 3 && (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) {
+            launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_CMAJOR>(a, st, false);
+            return;
+        }
+    }
     if ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST>(a, st, balance_tail);
     else if (d.KH * d.KW == 1) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST_KT>(a, st, balance_tail);
     else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC>(a, st, balance_tail);
@@ -655,7 +747,8 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
         else if (big == 2 && a.N >= 128) launch_igemm<256, 128, 4, 2, true>(a, st);
         else if (big == 3 && a.N >= 128) launch_igemm<128, 128, 2, 4, true>(a, st);      // 8 waves of 64x32: more waves per SIMD
         else if (a.N > 64 && deep_ns >= 3 && d->C0 % CV_BK == 0 && d->C1 % CV_BK == 0) {
-            if (deep_ns == 3) launch_igemm_deep<128, 128, 2, 2, true, 3>(a, st); else launch_igemm_deep<128, 128, 2, 2, true, 4>(a, st);
+            if (deep_ns == 3) launch_igemm_deep<128, 128, 2, 2, true, 3>(a, st);
+            else { if (deep_ns == 5) a.ablate = 5; launch_igemm_deep<128, 128, 2, 2, true, 4>(a, st); }
         }
         else if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st, getenv("SMIRK_TAIL_BALANCE") != nullptr);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
