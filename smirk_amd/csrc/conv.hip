@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 #define CV_BK 32
 
@@ -98,7 +99,14 @@ __device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 +
 //               (shifted) the same input pixels, so in this order the re-reads are L2 hits; tap-major order puts a whole pass over the
 //               channels (> the 4 MB L2 of an XCD) between them and every tap's rows come back from the Infinity Cache, whose ~7 TB/s
 //               (tools/igemm_micro.py) — not the matrix pipe — then sets the pace
-enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2, KW_CMAJOR = 3 };
+//   KW_LEAN     KW_FAST's walk with buffer-addressed DMA (`buffer_load_dwordx4 ... offen lds`): the per-lane part of every operand address is a
+//               32-bit VGPR offset that is constant for a whole (tap, source) segment, the advancing channel offset is a scalar, rows in the
+//               zero padding carry an out-of-range offset (the buffer unit returns zeros: no select, no zero page), the LDS destination
+//               (M0) is pure scalar arithmetic, and the loop is unrolled by two so the stage is a compile-time constant.  Cuts the ~54 VALU
+//               + 20 SALU per chunk and wave that KW_FAST spends on 64-bit pointers.
+//   KW_LEAN_CM  KW_CMAJOR's channel-major walk with KW_LEAN's buffer-addressed DMA (channel counts must be powers of two: the pixel index
+//               becomes a byte offset with one shift-add per row and chunk)
+enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2, KW_CMAJOR = 3, KW_LEAN = 4, KW_LEAN_CM = 5 };
 
 // one BM x BN output tile at (m0, n0); `smem` holds 2 pipeline stages of (BM + BN) x 32 dwords
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, int NS = 2>
@@ -170,7 +178,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     // ---- KW_CMAJOR: per staged row, the (reflected / clamped) pixel-row and column offsets of the three ky / kx, and a 9-bit tap validity mask
     int rowoff[PA][3], coloff[PA][3];
     unsigned vmask[PA];
-    if constexpr (KWALK == KW_CMAJOR) {
+    if constexpr (KWALK == KW_CMAJOR || KWALK == KW_LEAN_CM) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const int iy0 = pyx[p] >> 16, ix0 = (int)(short)(pyx[p] & 0xffff);
@@ -207,6 +215,91 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
         for (int p = 0; p < PB; ++p)
             __builtin_amdgcn_global_load_lds((gptr_t)(wb + wrow[p]), (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
     };
+
+#ifndef LEAN_M0_GUARD
+#define LEAN_M0_GUARD() asm volatile("s_nop 7" ::: "memory")
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type and builtins exist in the device pass only
+    // ---- KW_LEAN: buffer resources + per-lane byte offsets -------------------------------------------------------------------------
+    [[maybe_unused]] const int swave = __builtin_amdgcn_readfirstlane(wave);
+    [[maybe_unused]] unsigned voffA[PA], voffB[PB];
+    [[maybe_unused]] int sA = 0, sW = 0, lseg_left = 0, lseg_tap = 0, lseg_src = 0;
+    auto lean_rsrc = [&](const float* base, long long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
+    };
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs0 = lean_rsrc(a.in0, (long long)d.B * d.H * d.W * d.C0 * 4);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs1 = lean_rsrc(d.C1 > 0 ? a.in1 : a.in0, (long long)d.B * d.H * d.W * (d.C1 > 0 ? d.C1 : d.C0) * 4);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsw = lean_rsrc(a.w, (long long)a.N * a.K * 4);
+    if constexpr (KWALK == KW_LEAN || KWALK == KW_LEAN_CM) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) voffB[p] = (wrow[p] + (unsigned)col4 * 4u) * 4u;
+    }
+    auto open_segment_lean = [&]() {
+        const int ky = lseg_tap / d.KW, kx = lseg_tap - ky * d.KW;
+        const int cs = lseg_src ? d.C1 : d.C0;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int iy = (pyx[p] >> 16) + ky, ix = (int)(short)(pyx[p] & 0xffff) + kx;
+            bool ok = true;
+            if (d.pad_mode == SMIRK_PAD_REFLECT) { iy = reflect_idx(iy, d.H); ix = reflect_idx(ix, d.W); }
+            else ok = iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            iy = min(max(iy, 0), d.H - 1); ix = min(max(ix, 0), d.W - 1);
+            const unsigned off = ((unsigned)(boff[p] + iy * d.W + ix) * (unsigned)cs + (unsigned)col4 * 4u) * 4u;
+            voffA[p] = ok ? off : 0x80000000u;                   // beyond num_records: the load returns zeros
+        }
+        sA = 0;
+        sW = (lseg_tap * a.Cin + (lseg_src ? d.C0 : 0)) * 4;
+        lseg_left = cs / CV_BK;
+    };
+    auto issue_lean = [&](auto stc, bool src1) {
+        constexpr int ST = decltype(stc)::value;
+        float* As = smem + ST * STAGE;
+        float* Bs = As + BM * 32;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, voffA[p], sA, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, voffA[p], sA, 0, 0);
+            LEAN_M0_GUARD();
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+        {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(Bs + (swave * 8 + RP * p) * 32), 16, voffB[p], sW, 0, 0);
+            LEAN_M0_GUARD();
+        }
+        sA += CV_BK * 4; sW += CV_BK * 4;
+        --lseg_left;
+    };
+    // channel-major: chunk (cc, tap) with compile-time tap and stage
+    [[maybe_unused]] const int sh0 = 31 - __builtin_clz((unsigned)d.C0) + 2, sh1 = d.C1 > 0 ? 31 - __builtin_clz((unsigned)d.C1) + 2 : sh0;
+    auto issue_lean_cm = [&](int cc, auto tapc, auto stc) {
+        constexpr int TAP = decltype(tapc)::value, ST = decltype(stc)::value, KY = TAP / 3, KX = TAP % 3;
+        float* As = smem + ST * STAGE;
+        float* Bs = As + BM * 32;
+        const int c0 = cc * CV_BK;
+        const bool s1 = c0 >= d.C0;
+        const int sh = s1 ? sh1 : sh0, sa = (s1 ? c0 - d.C0 : c0) * 4, sw = (TAP * a.Cin + c0) * 4;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const unsigned off = ((unsigned)(rowoff[p][KY] + coloff[p][KX]) << sh) + (unsigned)col4 * 16u;
+            const unsigned vo = ((vmask[p] >> TAP) & 1u) ? off : 0x80000000u;
+            if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, vo, sa, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, vo, sa, 0, 0);
+            LEAN_M0_GUARD();
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(Bs + (swave * 8 + RP * p) * 32), 16, voffB[p], sw, 0, 0);
+            LEAN_M0_GUARD();
+        }
+    };
+    // a segment ends: next (tap, source)
+    auto lean_advance = [&]() {
+        if (d.C1 > 0 && lseg_src == 0) lseg_src = 1; else { lseg_src = 0; ++lseg_tap; }
+        open_segment_lean();
+    };
+
+#endif
 
     // ---- KW_FAST*: segment state ------------------------------------------------------------------------------------------------------
     const float* pa[PA];
@@ -355,6 +448,50 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             if (ch + 1 < nchunk) issue_generic((ch + 1) * CV_BK, (ch + 1) & 1);
             compute(smem + (ch & 1) * STAGE, smem + (ch & 1) * STAGE + BM * 32);
         }
+    } else if constexpr (KWALK == KW_LEAN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int nloop = d.KH * d.KW * (d.C0 / CV_BK + d.C1 / CV_BK);
+        open_segment_lean();
+        issue_lean(std::integral_constant<int, 0>{}, false);
+        for (int ch = 0; ch + 1 < nloop; ch += 2) {
+            if (lseg_left == 0) lean_advance();
+            chunk_ready();
+            issue_lean(std::integral_constant<int, 1>{}, lseg_src != 0);
+            compute(smem, smem + BM * 32);
+            const bool more = ch + 2 < nloop;
+            if (more && lseg_left == 0) lean_advance();
+            chunk_ready();
+            if (more) issue_lean(std::integral_constant<int, 0>{}, lseg_src != 0);
+            compute(smem + STAGE, smem + STAGE + BM * 32);
+        }
+        if (nloop & 1) {
+            chunk_ready();
+            compute(smem, smem + BM * 32);
+        }
+#endif
+    } else if constexpr (KWALK == KW_LEAN_CM) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int ncc = (d.C0 + d.C1) / CV_BK;                    // even (dispatch guarantees it): two chunks x 9 taps = 18 static (tap, stage) bodies
+        auto body = [&](int cc, auto tapc, auto parc) {           // chunk (cc, TAP) sits in stage (PAR*9 + TAP) & 1
+            constexpr int TAP = decltype(tapc)::value, PAR = decltype(parc)::value, ST = (PAR * 9 + TAP) & 1;
+            chunk_ready();
+            if constexpr (TAP < 8) issue_lean_cm(cc, std::integral_constant<int, TAP + 1>{}, std::integral_constant<int, ST ^ 1>{});
+            else if (cc + 1 < ncc) issue_lean_cm(cc + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, ST ^ 1>{});
+            compute(smem + ST * STAGE, smem + ST * STAGE + BM * 32);
+        };
+        auto nine = [&](int cc, auto parc) {
+            body(cc, std::integral_constant<int, 0>{}, parc); body(cc, std::integral_constant<int, 1>{}, parc);
+            body(cc, std::integral_constant<int, 2>{}, parc); body(cc, std::integral_constant<int, 3>{}, parc);
+            body(cc, std::integral_constant<int, 4>{}, parc); body(cc, std::integral_constant<int, 5>{}, parc);
+            body(cc, std::integral_constant<int, 6>{}, parc); body(cc, std::integral_constant<int, 7>{}, parc);
+            body(cc, std::integral_constant<int, 8>{}, parc);
+        };
+        issue_lean_cm(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        for (int cc = 0; cc < ncc; cc += 2) {
+            nine(cc, std::integral_constant<int, 0>{});
+            nine(cc + 1, std::integral_constant<int, 1>{});
+        }
+#endif
     } else if constexpr (KWALK == KW_CMAJOR) {
         const int ncc = (d.C0 + d.C1) / CV_BK;
         issue_cmajor(0, 0, 0);
@@ -688,6 +825,21 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st, bool balance_tail = 
     const SmirkConvDesc& d = a.d;
     // measured (B=128, same box, tap-major -> channel-major): 56x56 64->128 0.221 -> 0.201 ms, 128->128 0.367 -> 0.344, 256->128 0.725 -> 0.655;
     // 28x28 128->256 0.203 -> 0.184, 256->256 0.357 -> 0.336, 512->256 0.680 -> 0.652; 14x14 layers unchanged; 112x112 64->64 (128x64 tile) 0.51 -> 0.54
+    // default ON (measured, B=128, same box, old paths -> lean: 14x14x512 0.346 -> 0.327 ms, 28x28 512->256 0.665 -> 0.590, 56x56 256->128
+    // 0.715 -> 0.605, 112x112 64->64 0.50 -> 0.46); SMIRK_IGEMM_LEAN=0 restores the pointer-based K walks
+    static const char* lean_env = getenv("SMIRK_IGEMM_LEAN");
+    const bool lean = !(lean_env && lean_env[0] == '0');
+    if constexpr (SPLIT && WGM * WGN == 4) {
+        const long long b0 = (long long)d.B * d.H * d.W * d.C0 * 4, b1 = (long long)d.B * d.H * d.W * d.C1 * 4, bw = (long long)a.N * a.K * 4;
+        if (lean && (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0) && b0 < (1ll << 31) && b1 < (1ll << 31) && bw < (1ll << 31)) {
+            const bool pow2 = (d.C0 & (d.C0 - 1)) == 0 && (d.C1 & (d.C1 - 1)) == 0, even = ((d.C0 + d.C1) / CV_BK) % 2 == 0;
+            static const char* lcm_env = getenv("SMIRK_IGEMM_LEAN_CM");
+            const bool want_cm = lcm_env ? (lcm_env[0] != '0') : (BN == 128);
+            if (want_cm && d.KH == 3 && d.KW == 3 && pow2 && even) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN_CM>(a, st, false);
+            else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN>(a, st, false);
+            return;
+        }
+    }
     static const char* cm_env = getenv("SMIRK_IGEMM_CMAJOR");    // "0" forces tap-major, "1" forces channel-major everywhere it applies
     const bool cmajor = cm_env ? (cm_env[0] != '0') : (BN == 128 && d.Ho * d.Wo >= 400);
     if constexpr (SPLIT && WGM * WGN == 4) {
