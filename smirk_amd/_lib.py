@@ -168,10 +168,15 @@ def timed(kernel, flops, fn):
 
 
 def igemm_kernel_name(n_gemm, split=False, c0=32, c1=0, k=3):
-    """Which conv_igemm_kernel instantiation smirk_conv_igemm_{f32,f16x3} dispatches (mirrors conv.hip): tile by GEMM N, K-walk mode by
-    channel counts (1 = whole 32-channel chunks, 2 = 1x1 with a partial chunk, 0 = generic)."""
+    """Which conv_igemm_kernel instantiation smirk_conv_igemm_{f32,f16x3} dispatches (mirrors launch_igemm in conv.hip): tile by GEMM N,
+    K-walk mode by channel counts (0 generic, 1 tap-major pointer walk, 2 1x1 with a partial chunk, 4 buffer-addressed tap-major,
+    5 buffer-addressed channel-major).  Used for labelling timings only."""
     t = "128,128,2,2" if n_gemm > 64 else "128,64,2,2" if n_gemm > 32 else "256,32,4,1"
-    kw = 1 if (c0 % 32 == 0 and c1 % 32 == 0) else (2 if k == 1 else 0)
+    aligned = c0 % 32 == 0 and c1 % 32 == 0
+    kw = 1 if aligned else (2 if k == 1 else 0)
+    if split and aligned and os.environ.get("SMIRK_IGEMM_LEAN", "1") != "0":
+        pow2 = (c0 & (c0 - 1)) == 0 and (c1 & (c1 - 1)) == 0
+        kw = 5 if (k == 3 and pow2 and ((c0 + c1) // 32) % 2 == 0 and n_gemm > 64) else 4
     return f"conv_igemm_kernel<{t},{'true' if split else 'false'},{kw}>"
 
 
