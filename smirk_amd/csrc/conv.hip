@@ -109,7 +109,7 @@ __device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 +
 enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2, KW_CMAJOR = 3, KW_LEAN = 4, KW_LEAN_CM = 5 };
 
 // one BM x BN output tile at (m0, n0); `smem` holds 2 pipeline stages of (BM + BN) x 32 dwords
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, int NS = 2>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const int m0, const int n0) {
     constexpr int NW = WGM * WGN, NT = 64 * NW;                 // waves / threads per workgroup (4 or 8 waves)
     constexpr int RP = NT / 8;                                  // operand rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
@@ -117,8 +117,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     constexpr int PA = BM / RP, PB = BN / RP;
     constexpr int STAGE = (BM + BN) * 32;                       // dwords per pipeline stage
     constexpr int EPI_LD = TN * 32 + 4;                         // per-wave transpose buffer [32][EPI_LD] (vector epilogue)
-    static_assert(NW * 32 * EPI_LD <= NS * STAGE, "epilogue buffer must fit in the operand LDS");
-    static_assert(NS == 2 || KWALK == KW_FAST || KWALK == KW_FAST_KT, "the deep ring serves the channel-aligned tap-major K walks");
+    static_assert(NW * 32 * EPI_LD <= 2 * STAGE, "epilogue buffer must fit in the operand LDS");
     static_assert(BM % RP == 0 && BN % RP == 0, "tile must be a whole number of DMA passes");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,9 +215,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             __builtin_amdgcn_global_load_lds((gptr_t)(wb + wrow[p]), (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
     };
 
-#ifndef LEAN_M0_GUARD
-#define LEAN_M0_GUARD() asm volatile("s_nop 7" ::: "memory")
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource type and builtins exist in the device pass only
     // ---- KW_LEAN: buffer resources + per-lane byte offsets -------------------------------------------------------------------------
     [[maybe_unused]] const int swave = __builtin_amdgcn_readfirstlane(wave);
@@ -259,13 +255,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
         for (int p = 0; p < PA; ++p) {
             if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, voffA[p], sA, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, voffA[p], sA, 0, 0);
-            LEAN_M0_GUARD();
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p)
         {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(Bs + (swave * 8 + RP * p) * 32), 16, voffB[p], sW, 0, 0);
-            LEAN_M0_GUARD();
         }
         sA += CV_BK * 4; sW += CV_BK * 4;
         --lseg_left;
@@ -285,12 +279,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             const unsigned vo = ((vmask[p] >> TAP) & 1u) ? off : 0x80000000u;
             if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, vo, sa, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lptr_t)(As + (swave * 8 + RP * p) * 32), 16, vo, sa, 0, 0);
-            LEAN_M0_GUARD();
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(Bs + (swave * 8 + RP * p) * 32), 16, voffB[p], sw, 0, 0);
-            LEAN_M0_GUARD();
         }
     };
     // a segment ends: next (tap, source)
@@ -361,7 +353,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
 
     const int fr = lane & 31, hb = lane >> 5;
     // all LDS operand reads of a chunk (both 16-k steps) go out up front into two fragment sets, then the MFMAs
-    auto compute_h = [&](const float* As, const float* Bs, auto&& hook) {
+    auto compute = [&](const float* As, const float* Bs) {
         if constexpr (SPLIT) {
             half8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
@@ -378,11 +370,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                     bh[s][j] = *(const half8*)(Bs + lds_piece(row, pc)); bl[s][j] = *(const half8*)(Bs + lds_piece(row, pc + 1));
                 }
             }
-            // `hook(m)` runs after the m-th of the 6*TM*TN MFMAs: the next chunk's operand DMAs are dropped between them IN PROGRAM
-            // ORDER — a DMA writes LDS, so the compiler never moves one above an earlier ds_read and would otherwise keep all of them
-            // in front of the fragment reads, i.e. in front of every MFMA of the chunk
-            int m = 0;
-            hook(0);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -390,11 +377,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[0][i][j], 0, 0, 0);
-                        hook(++m);
                         acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[NACC - 1][i][j], 0, 0, 0);
-                        hook(++m);
                         acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[NACC - 1][i][j], 0, 0, 0);
-                        hook(++m);
                     }
         } else {
 #pragma unroll
@@ -414,30 +398,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             }
         }
     };
-    auto compute = [&](const float* As, const float* Bs) { compute_h(As, Bs, [](int) {}); };
     auto chunk_ready = [&]() {
         // chunk data has landed once THIS wave's DMAs retire and every wave has passed the barrier; the barrier also means every wave
         // finished reading the other stage (used by the previous chunk), so it may be refilled right away, under the MFMAs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
-    };
-
-    // one operand-DMA instruction of the next chunk (slot q of PA + PB), pointer bumps after the last one
-    [[maybe_unused]] auto issue_slot = [&](int st, int q) {
-        float* As = smem + st * STAGE;
-        float* Bs = As + BM * 32;
-        const bool kv = (KWALK == KW_FAST_KT) ? (kleft > 0) : true;
-        if (q < PA) {
-            const float* g = (KWALK == KW_FAST_KT) ? psel(kv, pa[q], g_zero16) : pa[q];
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(As + (wave * 8 + RP * q) * 32), 16, 0, 0);
-            pa[q] += inca[q];
-        } else {
-            const int p = q - PA;
-            const float* g = (KWALK == KW_FAST_KT) ? psel(kv, pbase + wrow[p], g_zero16) : pbase + wrow[p];
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Bs + (wave * 8 + RP * p) * 32), 16, 0, 0);
-        }
-        if (q == PA + PB - 1) { pbase += CV_BK; kleft -= CV_BK; --seg_left; }
     };
 
     if constexpr (KWALK == KW_GENERIC) {
@@ -507,61 +473,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                 compute(As, As + BM * 32);
             }
         }
-    } else if constexpr (NS > 2) {
-        // Deep ring (one workgroup per CU, NS stages): NS-1 chunks of operands are in flight while one is being consumed.  The L2->LDS
-        // stream is latency-bound (bytes in flight / ~1 us), so with one chunk in flight per workgroup the operand delivery, not the
-        // matrix pipe, sets the pace (measured: DMA alone 0.235 ms vs 0.14 ms of MFMA work on the 14x14x512 layers).
-        const int nloop = d.KH * d.KW * ((d.C0 + CV_BK - 1) / CV_BK + (d.C1 + CV_BK - 1) / CV_BK);
-        constexpr int INFLIGHT = (NS - 2) * (PA + PB);          // DMA instructions of the NS-2 younger chunks that may stay outstanding
-        static_assert(INFLIGHT == 8 || INFLIGHT == 16 || INFLIGHT == 6 || INFLIGHT == 12, "add the s_waitcnt literal for this tile");
-        auto chunk_ready_deep = [&]() {
-            if constexpr (INFLIGHT == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if constexpr (INFLIGHT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        if (a.ablate == 5 && NS == 4 && (nloop & 1) == 0) {
-            // "BK = 64" mode: the 4 stages form two double-stages; one barrier per TWO 32-k chunks (48 MFMAs per wave between barriers), so
-            // the per-barrier bubble (barrier skew + first fragment reads + DMA issue) is paid half as often
-            open_segment(); issue_fast(0);
-            if (seg_left == 0) open_segment();
-            issue_fast(1);
-            for (int ch = 0; ch < nloop; ch += 2) {
-                const bool more = ch + 2 < nloop;
-                if (more && seg_left == 0) open_segment();
-                chunk_ready();
-                const float* A0 = smem + (ch % NS) * STAGE;
-                const float* A1 = smem + ((ch + 1) % NS) * STAGE;
-                if (more) {
-                    issue_fast((ch + 2) % NS);
-                    if (seg_left == 0) open_segment();
-                    issue_fast((ch + 3) % NS);
-                }
-                compute(A0, A0 + BM * 32);
-                compute(A1, A1 + BM * 32);
-            }
-        } else {
-        int issued = 0;
-        for (; issued < NS - 1 && issued < nloop; ++issued) {
-            if (seg_left == 0) open_segment();
-            issue_fast(issued % NS);
-        }
-        int ch = 0;
-        for (; ch + (NS - 1) < nloop; ++ch) {                    // steady state: every iteration issues chunk ch + NS - 1
-            if (seg_left == 0) open_segment();
-            chunk_ready_deep();
-            const float* As = smem + (ch % NS) * STAGE;
-            issue_fast((ch + NS - 1) % NS);                      // refills the stage chunk ch-1 used: every wave is past it (barrier above)
-            compute(As, As + BM * 32);
-        }
-        for (; ch < nloop; ++ch) {                               // drain: nothing left to issue
-            chunk_ready();
-            const float* As = smem + (ch % NS) * STAGE;
-            compute(As, As + BM * 32);
-        }
-        }
     } else {
         const int nloop = d.KH * d.KW * ((d.C0 + CV_BK - 1) / CV_BK + (d.C1 + CV_BK - 1) / CV_BK);
         open_segment();
@@ -570,45 +481,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
             if (seg_left == 0) open_segment();                   // rare (once per tap / source), before the hot block
             chunk_ready();
             const float* As = smem + (ch & 1) * STAGE;
-#ifdef SMIRK_DMA_AFTER_READS
-            if constexpr (SPLIT && KWALK != KW_GENERIC) {
-                constexpr int NM = 6 * TM * TN, NSLOT = PA + PB;
-                const int nst = (ch + 1) & 1;
-                (void)NM;
-                compute_h(As, As + BM * 32, [&](int m) {       // m == 0: after the fragment reads were issued, before the first MFMA
-                    if (m == 0) {
-#pragma unroll
-                        for (int q = 0; q < NSLOT; ++q) issue_slot(nst, q);
-                    }
-                });
-                // pin the order: every fragment read, then the DMAs (their issue slots overlap the LDS latency), then the MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, NSLOT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-            } else
-#endif
-            {
-                issue_fast((ch + 1) & 1);
-                compute(As, As + BM * 32);
-            }
-#ifdef SMIRK_SCHED_PIPE
-            if constexpr (SPLIT && TM == 2 && TN == 2 && PA + PB == 8) {
-                // order of the block: k-step-0 fragments, then the 24 MFMAs with one operand DMA after every third of them (and the
-                // k-step-1 fragment reads under the first twelve) instead of all eight DMAs up front
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
-#endif
+            issue_fast((ch + 1) & 1);
+            compute(As, As + BM * 32);
         }
         chunk_ready();
         compute(smem + ((nloop - 1) & 1) * STAGE, smem + ((nloop - 1) & 1) * STAGE + BM * 32);
@@ -728,31 +602,9 @@ template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
 __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN == 128 * 128 && WGM * WGN == 8) ? 4 : 2) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
     const int ntn = (a.N + BN - 1) / BN;
-    int mt, nt;
-    if (a.ablate == 2) {
-        // weight-panel-per-XCD order (ntn in {1,2,4,8}): XCD x keeps ONE BN-column weight panel (BN x K x 4 B, e.g. 2.4 MB for 512x3x3)
-        // in its 4 MB L2 for the whole launch and walks a contiguous range of M tiles; with the n-fastest order an XCD's resident
-        // workgroups touch every panel at once (9.4 MB for Cout = 512) and each of them streams its operands from the Infinity Cache
-        const int ntm = (a.M + BM - 1) / BM, groups = 8 / ntn;
-        const int x = blockIdx.x & 7, t = blockIdx.x >> 3, g = x / ntn;
-        const int m0 = (g * ntm) / groups, m1 = ((g + 1) * ntm) / groups;
-        if (t >= m1 - m0) return;
-        nt = x % ntn;
-        mt = m0 + t;
-    } else {
-        const int logical = xcd_logical(blockIdx.x, gridDim.x);
-        mt = logical / ntn; nt = logical % ntn;
-    }
-    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, mt * BM, nt * BN);
-}
-
-// Deep-ring variant: NS operand stages in dynamic LDS, one workgroup per CU (see conv_tile).
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, int NS>
-__global__ __launch_bounds__(64 * WGM * WGN, 1) void conv_igemm_deep_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float dsmem[];
-    const int ntn = (a.N + BN - 1) / BN;
     const int logical = xcd_logical(blockIdx.x, gridDim.x);
-    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK, NS>(a, dsmem, (logical / ntn) * BM, (logical % ntn) * BN);
+    const int mt = logical / ntn, nt = logical % ntn;
+    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, mt * BM, nt * BN);
 }
 
 // Tail balancing.  When the tile count leaves a short last round (e.g. 784 tiles on 512 resident slots), the first a.mfull M-tiles are
@@ -798,26 +650,7 @@ static void launch_igemm_kw(ConvArgs a, hipStream_t st, bool balance_tail) {
             }
         }
     }
-    static const bool panel_order = getenv("SMIRK_IGEMM_PANEL_ORDER") != nullptr;
-    if (panel_order && (ntn == 1 || ntn == 2 || ntn == 4 || ntn == 8) && ntm >= 64) {
-        const int groups = 8 / ntn;
-        a.ablate = 2;
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(8 * ((ntm + groups - 1) / groups)), dim3(64 * WGM * WGN), 0, st, a);
-        return;
-    }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
-}
-
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int NS>
-static void launch_igemm_deep(const ConvArgs& a, hipStream_t st) {
-    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    const size_t lds = (size_t)NS * (BM + BN) * 32 * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_deep_kernel<BM, BN, WGM, WGN, SPLIT, KW_FAST, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL((conv_igemm_deep_kernel<BM, BN, WGM, WGN, SPLIT, KW_FAST, NS>), dim3(ntm * ntn), dim3(64 * WGM * WGN), lds, st, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
@@ -892,16 +725,10 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
     static const char* big_env = getenv("SMIRK_IGEMM_8WAVE");
     const int big = big_env ? atoi(big_env) : 0;                 // tuning switch: 8-wave 128x256 / 256x128 tiles
-    static const char* deep_env = getenv("SMIRK_IGEMM_STAGES");
-    const int deep_ns = deep_env ? atoi(deep_env) : 0;           // 3 | 4: deep operand ring, one workgroup per CU
     if (split) {
         if (big == 1 && a.N >= 256) launch_igemm<128, 256, 2, 4, true>(a, st);
         else if (big == 2 && a.N >= 128) launch_igemm<256, 128, 4, 2, true>(a, st);
         else if (big == 3 && a.N >= 128) launch_igemm<128, 128, 2, 4, true>(a, st);      // 8 waves of 64x32: more waves per SIMD
-        else if (a.N > 64 && deep_ns >= 3 && d->C0 % CV_BK == 0 && d->C1 % CV_BK == 0) {
-            if (deep_ns == 3) launch_igemm_deep<128, 128, 2, 2, true, 3>(a, st);
-            else { if (deep_ns == 5) a.ablate = 5; launch_igemm_deep<128, 128, 2, 2, true, 4>(a, st); }
-        }
         else if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st, getenv("SMIRK_TAIL_BALANCE") != nullptr);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
         else launch_igemm<256, 32, 4, 1, true>(a, st);
