@@ -42,6 +42,24 @@ __device__ __forceinline__ const float* psel_p(bool c, const float* p, const flo
     return (const float*)(((unsigned long long)p & m) | ((unsigned long long)q & ~m));
 }
 
+
+// buffer-addressed halo DMA (see conv.hip KW_LEAN): the per-lane part of a halo pixel's address is (patch-relative pixel << log2(4 C)) + piece,
+// constant across patches; the patch origin is scalar; pixels outside the image carry an out-of-range offset and come back as zeros
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PATCH_BUF_DECL()                                                                                                             \
+    const __amdgpu_buffer_rsrc_t brs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, (short)0, a.use_buf ? a.B * a.H * a.W * a.C0 * 4 : 0, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t brs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.C1 > 0 ? a.in1 : a.in0), (short)0,               \
+                                                                          a.use_buf ? a.B * a.H * a.W * (a.C1 > 0 ? a.C1 : a.C0) * 4 : 0, 0x00020000); \
+    const int bsh0 = 33 - __builtin_clz((unsigned)a.C0), bsh1 = a.C1 > 0 ? 33 - __builtin_clz((unsigned)a.C1) : bsh0;                  \
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+#define PATCH_BUF_LOAD(S1, LDS, VOFF, SOFF)                                                                                          \
+    do { if (S1) __builtin_amdgcn_raw_ptr_buffer_load_lds(brs1, (lptr_t)(LDS), 16, VOFF, SOFF, 0, 0);                                 \
+         else __builtin_amdgcn_raw_ptr_buffer_load_lds(brs0, (lptr_t)(LDS), 16, VOFF, SOFF, 0, 0); } while (0)
+#else
+#define PATCH_BUF_DECL() const int bsh0 = 0, bsh1 = 0, swave = 0; (void)bsh0; (void)bsh1; (void)swave;
+#define PATCH_BUF_LOAD(S1, LDS, VOFF, SOFF) do { (void)(VOFF); } while (0)
+#endif
+
 struct PatchArgs {
     const float *in0, *in1, *w, *scale, *shift;
     float* out;
@@ -54,6 +72,7 @@ struct PatchArgs {
     const float *fw, *fb;
     float* fout;
     int fcout;
+    int use_buf;     // operand DMA through buffer resources (32-bit per-lane offsets, OOB rows for the zero padding): C0, C1 powers of two, tensors < 2 GiB
 };
 
 __device__ __forceinline__ int lds_piece_p(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
@@ -116,6 +135,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
         oy0 = (t / tiles_x) * PT;
         ox0 = (t - (t / tiles_x) * tiles_x) * PT;
     };
+    PATCH_BUF_DECL()
     auto issue_item = [&](int item, int st) {
         int b, oy0, ox0, cc;
         item_patch(item, b, oy0, ox0, cc);
@@ -124,6 +144,20 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
         const float* src = s1 ? a.in1 : a.in0;
         const int cs = s1 ? a.C1 : a.C0, cb = s1 ? c0 - a.C0 : c0;
         float* dst = St + st * PSTAGE;
+        if (a.use_buf) {
+            const int basepix = (b * a.H + oy0 - 1) * a.W + ox0 - 1, sh = s1 ? bsh1 : bsh0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if ((q * 4 + swave) * 8 < PPIX) {
+                    const int pix = (q * 4 + wave) * 8 + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
+                    const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                    const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (cb + piece * 4) < cs;
+                    const unsigned vo = ok ? ((unsigned)(basepix + hp_y[q] * a.W + hp_x[q]) << sh) + (unsigned)piece * 16u : 0x80000000u;
+                    PATCH_BUF_LOAD(s1, dst + (q * 4 + swave) * 8 * 32, vo, cb * 4);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int pixbase = (q * 4 + wave) * 8;
@@ -311,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         oy0 = (t / tiles_x) * PT;
         ox0 = (t - (t / tiles_x) * tiles_x) * PT;
     };
+    PATCH_BUF_DECL()
     auto issue_input = [&](int p, int cc, int st) {
         int b, oy0, ox0;
         patch_origin(p, b, oy0, ox0);
@@ -319,6 +354,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         const float* src = s1 ? a.in1 : a.in0;
         const int cs = s1 ? a.C1 : a.C0, cb = s1 ? c0 - a.C0 : c0;
         float* dst = St + st * PSTAGE;
+        if (a.use_buf) {
+            const int basepix = (b * a.H + oy0 - 1) * a.W + ox0 - 1, sh = s1 ? bsh1 : bsh0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if ((q * 4 + swave) * 8 < PPIX) {
+                    const int pix = (q * 4 + wave) * 8 + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
+                    const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                    const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    const unsigned vo = ok ? ((unsigned)(basepix + hp_y[q] * a.W + hp_x[q]) << sh) + (unsigned)piece * 16u : 0x80000000u;
+                    PATCH_BUF_LOAD(s1, dst + (q * 4 + swave) * 8 * 32, vo, cb * 4);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int pixbase = (q * 4 + wave) * 8;
@@ -480,6 +529,12 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
     a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
     a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
     a.npatch = d->B * (d->H / PT) * (d->W / PT);
+    {
+        static const char* nb = getenv("SMIRK_PATCH_NO_BUFFER_DMA");
+        const long long px = (long long)d->B * d->H * d->W;
+        const bool pow2 = (d->C0 & (d->C0 - 1)) == 0 && (d->C1 & (d->C1 - 1)) == 0;
+        a.use_buf = (!nb && pow2 && px * d->C0 * 4 < (1ll << 31) && px * d->C1 * 4 < (1ll << 31)) ? 1 : 0;
+    }
     if (!patch_resident(d)) {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void*)conv3x3_patch_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
