@@ -24,8 +24,16 @@
 //   F16X3 epilogue transposes each wave's tile through LDS so every lane stores whole 8-channel groups (2 x 16 bytes).
 // * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous run of tiles, so blocks that share an A row
 //   panel or a weight panel hit the same private L2.
+// * K is walked in one of several orders / addressing schemes (enum KW_* below).  The shipped defaults for channel-aligned layers are
+//   the buffer-addressed walks: operands arrive through `buffer_load_dwordx4 ... offen lds` with a per-lane 32-bit offset that is
+//   constant per (tap, source) segment, a scalar channel offset, an out-of-range offset for rows in the zero padding (the buffer unit
+//   writes zeros), scalar LDS destinations and a loop unrolled by two — no vector ALU work between the barrier and the first fragment
+//   read.  3x3 layers on the 128x128 tile walk K channel-chunk-major (the 9 taps of a 32-channel chunk back to back) so that the
+//   shifted re-reads of the same input pixels hit L2: measured with tools/igemm_micro.py, the hot loop runs a chunk in 1300 cycles on
+//   L2-resident operands but 2850 when they come back from the Infinity Cache.
 //
-// Bound: MFMA (fp32 157.3 TF; f16 2.5 PF issuing 3 MFMA-flop per algorithmic flop).  Algorithmic flop = 2*M*N*K.
+// Bound: MFMA (fp32 157.3 TF; f16 2.5 PF issuing 3 MFMA-flop per algorithmic flop) once the operands hit L2; the Infinity Cache's
+// ~7 TB/s otherwise.  Algorithmic flop = 2*M*N*K.
 #include <stdlib.h>
 
 #include "common.h"
