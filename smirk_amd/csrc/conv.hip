@@ -409,7 +409,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     auto chunk_ready = [&]() {
         // chunk data has landed once THIS wave's DMAs retire and every wave has passed the barrier; the barrier also means every wave
         // finished reading the other stage (used by the previous chunk), so it may be refilled right away, under the MFMAs
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // vmcnt: this wave's DMAs of the chunk have landed.  lgkmcnt: this wave's fragment reads of the PREVIOUS chunk have completed —
+        // the compiler may sink their consumers (MFMAs) below the barrier, and the stage they read is refilled right after it
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
     };

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
     while (item < nitem) {
         int b, oy0, ox0, cc;
         item_patch(item, b, oy0, ox0, cc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + this wave's LDS reads of the stage about to be refilled
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
         // stage st (and, first time, the weights) has landed
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         }
     };
     auto stage_ready = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + this wave's LDS reads of the stage about to be refilled
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
