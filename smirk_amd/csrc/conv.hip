@@ -49,7 +49,6 @@ struct ConvArgs {
     float* out;
     int M, N, K, Cin;
     int ablate;    // reserved for ablation experiments (unused in the shipped kernels)
-    int mfull;     // conv_igemm_mixed_kernel: number of full-height M tiles (the remaining rows use half-height tiles)
     int psh;       // GEMM rows enumerate each image in (2^psh x 2^psh)-pixel patches (tile-major): a BM-row tile is then a compact 2-D
                    // patch whose 3x3 halo is ~1.3x its area instead of 3 full image rows — the im2col re-reads stay in L1/L2
 };
@@ -609,7 +608,7 @@ __device__ __forceinline__ int xcd_logical(int id, int nblk) {
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
-__global__ __launch_bounds__(64 * WGM * WGN, (BM * BN == 128 * 128 && WGM * WGN == 8) ? 4 : 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
     const int ntn = (a.N + BN - 1) / BN;
     const int logical = xcd_logical(blockIdx.x, gridDim.x);
@@ -617,54 +616,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN == 128 * 128 && WGM * WGN 
     conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, mt * BM, nt * BN);
 }
 
-// Tail balancing.  When the tile count leaves a short last round (e.g. 784 tiles on 512 resident slots), the first a.mfull M-tiles are
-// full BM x BN tiles and the rest of M is cut into BM/2 x BN tiles launched AFTER them in the same grid: the last round then takes half
-// the time (1.5 instead of 2 rounds for the 14x14 layers).  Results are identical — every output element still sees the same K order.
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_mixed_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
-    const int ntn = (a.N + BN - 1) / BN;
-    const int nfull = a.mfull * ntn;
-    if ((int)blockIdx.x < nfull) {
-        const int logical = xcd_logical(blockIdx.x, nfull);
-        conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, (logical / ntn) * BM, (logical % ntn) * BN);
-    } else {
-        const int logical = xcd_logical(blockIdx.x - nfull, gridDim.x - nfull);
-        conv_tile<BM / 2, BN, WGM, WGN, SPLIT, KWALK>(a, smem, a.mfull * BM + (logical / ntn) * (BM / 2), (logical % ntn) * BN);
-    }
-}
-
-static int resident_slots() {                                    // 2 workgroups per CU for the 128x128 tile (LDS 2 x 64 KiB, <= 256 VGPRs)
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 2 * (cus > 0 ? cus : 256);
-    }
-    return slots;
-}
-
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
-static void launch_igemm_kw(ConvArgs a, hipStream_t st, bool balance_tail) {
+static void launch_igemm_kw(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    if constexpr (BM / WGM >= 64 && WGM * WGN == 4) {
-        if (balance_tail) {
-            const int slots = resident_slots(), total = ntm * ntn;
-            const int rounds = total / slots, rem = total - rounds * slots;
-            // worth it when the last round is at most 3/4 full and there is at least one full round before it
-            if (rounds >= 1 && rem > 0 && 4 * rem <= 3 * slots && slots % ntn == 0) {
-                a.mfull = rounds * slots / ntn;
-                const int nhalf = (a.M - a.mfull * BM + BM / 2 - 1) / (BM / 2) * ntn;
-                hipLaunchKernelGGL((conv_igemm_mixed_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(a.mfull * ntn + nhalf), dim3(64 * WGM * WGN), 0, st, a);
-                return;
-            }
-        }
-    }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
-static void launch_igemm(const ConvArgs& a, hipStream_t st, bool balance_tail = false) {
+static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     const SmirkConvDesc& d = a.d;
     // measured (B=128, same box, tap-major -> channel-major): 56x56 64->128 0.221 -> 0.201 ms, 128->128 0.367 -> 0.344, 256->128 0.725 -> 0.655;
     // 28x28 128->256 0.203 -> 0.184, 256->256 0.357 -> 0.336, 512->256 0.680 -> 0.652; 14x14 layers unchanged; 112x112 64->64 (128x64 tile) 0.51 -> 0.54
@@ -678,8 +637,8 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st, bool balance_tail = 
             const bool pow2 = (d.C0 & (d.C0 - 1)) == 0 && (d.C1 & (d.C1 - 1)) == 0, even = ((d.C0 + d.C1) / CV_BK) % 2 == 0;
             static const char* lcm_env = getenv("SMIRK_IGEMM_LEAN_CM");
             const bool want_cm = lcm_env ? (lcm_env[0] != '0') : (BN == 128);
-            if (want_cm && d.KH == 3 && d.KW == 3 && pow2 && even) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN_CM>(a, st, false);
-            else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN>(a, st, false);
+            if (want_cm && d.KH == 3 && d.KW == 3 && pow2 && even) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN_CM>(a, st);
+            else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN>(a, st);
             return;
         }
     }
@@ -687,13 +646,13 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st, bool balance_tail = 
     const bool cmajor = cm_env ? (cm_env[0] != '0') : (BN == 128 && d.Ho * d.Wo >= 400);
     if constexpr (SPLIT && WGM * WGN == 4) {
         if (cmajor && d.KH == 3 && d.KW == 3 && (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) {
-            launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_CMAJOR>(a, st, false);
+            launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_CMAJOR>(a, st);
             return;
         }
     }
-    if ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST>(a, st, balance_tail);
-    else if (d.KH * d.KW == 1) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST_KT>(a, st, balance_tail);
-    else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC>(a, st, balance_tail);
+    if ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST>(a, st);
+    else if (d.KH * d.KW == 1) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST_KT>(a, st);
+    else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC>(a, st);
 }
 
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
@@ -725,7 +684,6 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     if (M > (1ll << 30) || (long long)d->B * d->H * d->W > (1ll << 30)) return SMIRK_ERR_UNSUPPORTED;
     a.M = (int)M;
     a.ablate = 0;
-    a.mfull = 0;
     a.psh = 0;
     if (d->KH == 3)                                             // only convs with a halo profit from patch ordering
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
@@ -733,13 +691,8 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
     if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
-    static const char* big_env = getenv("SMIRK_IGEMM_8WAVE");
-    const int big = big_env ? atoi(big_env) : 0;                 // tuning switch: 8-wave 128x256 / 256x128 tiles
     if (split) {
-        if (big == 1 && a.N >= 256) launch_igemm<128, 256, 2, 4, true>(a, st);
-        else if (big == 2 && a.N >= 128) launch_igemm<256, 128, 4, 2, true>(a, st);
-        else if (big == 3 && a.N >= 128) launch_igemm<128, 128, 2, 4, true>(a, st);      // 8 waves of 64x32: more waves per SIMD
-        else if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st, getenv("SMIRK_TAIL_BALANCE") != nullptr);
+        if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
         else launch_igemm<256, 32, 4, 1, true>(a, st);
     } else {
