@@ -299,3 +299,33 @@ def test_video_oracle_known_answers():
     u = np.arange(256, dtype=np.uint8)
     rq = V.to_u8(V.from_u8(u))
     assert (np.abs(rq.astype(int) - u) <= 1).all() and (rq == u).mean() > 0.9               # float32 /255 *255 truncation: a few values drop by 1
+
+
+def test_barycentric_backward_three_derivations_agree():
+    """The renderer-backward oracle differentiates pytorch3d's barycentric formula with autograd; pytorch3d itself uses a hand-written
+    backward.  Its restatement (oracle/render_torch_ref.py::barycentric_backward_p3d), autograd and central finite differences must agree."""
+    import torch
+    from oracle.render_torch_ref import K_EPS, barycentric_backward_p3d
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        tri = rng.uniform(-1, 1, (3, 2)); p = tri.mean(0) + rng.uniform(-0.05, 0.05, 2); g = rng.standard_normal(3)
+        def bary(pts):
+            v0, v1, v2 = pts[0], pts[1], pts[2]
+            e = lambda a, b, c: (a[0] - b[0]) * (c[1] - b[1]) - (a[1] - b[1]) * (c[0] - b[0])
+            area = e(v2, v0, v1) + K_EPS
+            return torch.stack([e(p_t, v1, v2), e(p_t, v2, v0), e(p_t, v0, v1)]) / area
+        p_t = torch.tensor(p, dtype=torch.float64)
+        pts = torch.tensor(tri, dtype=torch.float64, requires_grad=True)
+        (bary(pts) * torch.tensor(g)).sum().backward()
+        auto = pts.grad.numpy()
+        _, g0, g1, g2 = barycentric_backward_p3d(p, tri[0], tri[1], tri[2], g)
+        hand = np.stack([g0, g1, g2])
+        fd = np.zeros((3, 2))
+        for i in range(3):
+            for j in range(2):
+                d = np.zeros((3, 2)); d[i, j] = 1e-6
+                with torch.no_grad():
+                    fd[i, j] = (((bary(torch.tensor(tri + d)) - bary(torch.tensor(tri - d))) * torch.tensor(g)).sum() / 2e-6).item()
+        scale = max(1.0, np.abs(auto).max())
+        assert np.abs(auto - hand).max() < 1e-9 * scale
+        assert np.abs(auto - fd).max() < 1e-4 * scale
