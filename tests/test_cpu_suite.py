@@ -329,3 +329,24 @@ def test_barycentric_backward_three_derivations_agree():
         scale = max(1.0, np.abs(auto).max())
         assert np.abs(auto - hand).max() < 1e-9 * scale
         assert np.abs(auto - fd).max() < 1e-4 * scale
+
+
+def test_video_warp_restatement_agrees_with_scipy_bilinear():
+    """oracle/video_ref.warp_u8 restates skimage.transform.warp(order=1, mode='constant', cval=0) (skimage is not on disk).  scipy IS on
+    disk: ndimage.map_coordinates(order=1, mode='grid-constant') is the same bilinear-with-zero-neighbours rule — an independent cross-check
+    of the interpolation semantics (floor/ceil neighbours, zero outside), up to the final truncation to uint8."""
+    from scipy import ndimage
+    from oracle import video_ref as V
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for _ in range(4):
+        s, a = rng.uniform(0.5, 2.0), rng.uniform(-0.6, 0.6)
+        M = np.array([[s * np.cos(a), -s * np.sin(a), rng.uniform(-10, 20)], [s * np.sin(a), s * np.cos(a), rng.uniform(-10, 20)], [0, 0, 1]])
+        Ho, Wo = 41, 47
+        got = V.warp_u8(img, M, (Ho, Wo))
+        cc, rr = np.meshgrid(np.arange(Wo, dtype=np.float64), np.arange(Ho, dtype=np.float64))
+        x = M[0, 0] * cc + M[0, 1] * rr + M[0, 2]
+        y = M[1, 0] * cc + M[1, 1] * rr + M[1, 2]
+        ref = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64), [y, x], order=1, mode="grid-constant", cval=0.0) for c in range(3)], -1)
+        d = np.abs(got.astype(np.float64) - np.floor(ref + 1e-9))
+        assert (d > 0).mean() < 2e-3 and d.max() <= 1        # identical up to truncation ties at exact integers
