@@ -350,3 +350,15 @@ def test_video_warp_restatement_agrees_with_scipy_bilinear():
         ref = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64), [y, x], order=1, mode="grid-constant", cval=0.0) for c in range(3)], -1)
         d = np.abs(got.astype(np.float64) - np.floor(ref + 1e-9))
         assert (d > 0).mean() < 2e-3 and d.max() <= 1        # identical up to truncation ties at exact integers
+
+
+def test_video_convex_hull_agrees_with_scipy():
+    """oracle/video_ref.convex_hull (the hull create_mask fills, cv2.convexHull in the reference) vs scipy.spatial.ConvexHull (qhull)."""
+    from scipy.spatial import ConvexHull
+    from oracle import video_ref as V
+    rng = np.random.default_rng(11)
+    for _ in range(5):
+        pts = rng.integers(0, 224, (478, 2))
+        mine = {tuple(p) for p in V.convex_hull(pts).tolist()}
+        ref = {tuple(pts[i].tolist()) for i in ConvexHull(pts.astype(np.float64)).vertices}
+        assert mine == ref
