@@ -1,245 +1,595 @@
 #!/usr/bin/env python
 """bench.py — faces/sec of SMIRK's per-frame hot path (encode -> FLAME -> render -> generate) at 224x224 on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_PER_GPU]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|infer256|flame512] [--global-batch G | --batch B_PER_GPU]
 
-One "step" = one pass of the whole path over `--batch` synthetic frames per GPU (default 128 = BASELINE config 4's 1024-frame
-batch sharded over 8 GPUs; weak scaling), inputs resident in HBM, followed by the asynchronous RCCL all-gather of the outputs
-(vertices + rendered + re-synthesised image) which overlaps the next step.  Rank 0 prints ONE JSON line (contract in the task
-statement) carrying `roofline` for the dominant kernel (HIP-event timing of every conv_igemm launch in an extra instrumented step)
-and `cpu_baseline` (the CPU oracle — a port of the reference path — timed on this box's host cores on a bounded sample).
+`--gpus N` with N > 1 launches itself as N ranks (one process per GPU, torch.distributed.run, rendezvous on 127.0.0.1); when the driver
+already started it under torch.distributed.run (RANK / WORLD_SIZE set) it just joins.
+
+Workloads (BASELINE.json configs):
+  full      config 4 — full inference incl. SmirkGenerator re-synthesis on a 1024-frame batch: the batch is sharded in contiguous slices
+            over the N ranks (strong scaling: 1024 frames per step in total, whatever N is), every rank walks its shard in micro-batches of
+            128 frames, and the outputs (vertices + rendered + re-synthesised image) are all-gathered with RCCL, asynchronously, so that the
+            gather of one micro-batch overlaps the compute of the next.  `--batch B` instead fixes B frames PER GPU (weak scaling).
+  infer256  config 3 — encoder + FLAME + renderer, 256 frames.
+  flame512  config 2 — FLAME only, 512 random parameter vectors -> 5023 vertices.
+One "step" = one pass of the workload over its batch, inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`roofline`: every kernel launch of one extra instrumented step is bracketed by HIP events on its launch stream inside libsmirk_hip.so /
+the ctypes layer; the dominant kernel's ALGORITHMIC flop (2*M*N*K) per launch / its mean launch time is `achieved`.  `traffic` comes from
+two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) that this script starts on itself (`--traffic measure`, the default
+on one GPU), corrected as MI355X_MICROARCH.md prescribes for gfx950 (2*FETCH_SIZE + WRITE_SIZE, KiB units).
+`cpu_baseline`: the CPU oracle (a port of the reference path) timed on this box's host cores on a bounded sample — checker code,
+reported beside the GPU number.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import shutil
+import socket
+import statistics
+import subprocess
 import sys
 import tempfile
 import time
-
-import torch
-import torch.distributed as dist
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_FACE = 28.77e9          # encoder 0.929 G + FLAME 12.7 M + render ~2 M + generator 27.826 G
+FLOP_PER_FACE_INFER = 0.929e9 + 12.7e6 + 2e6
+FLOP_PER_FACE_FLAME = 12.7e6
 PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA = 2500e12          # MI355X_MICROARCH.md: bf16/fp16 dense MFMA peak (the f16x3 kernel issues 3 MFMA-flop per algorithmic flop)
+PEAK_HBM = 8.0e12
+MICRO_BATCH = 128                # frames per pass of the path (activations peak ~8 GB per 128 frames; 32-bit buffer offsets stay valid)
+METRIC = {"full": "faces/sec (encode+FLAME+render+generate) @224x224",
+          "infer256": "faces/sec (encode+FLAME+render) @224x224",
+          "flame512": "faces/sec (FLAME-only: shape,exp,pose,jaw -> 5023 vertices)"}
 
 
-def build_modules(sandbox, device):
-    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator
-    from smirk_amd import synth
-    synth.write_sandbox(sandbox)
-    cwd = os.getcwd()
-    os.chdir(sandbox)
-    try:
-        flame, rend = FLAME(), Renderer()
-    finally:
-        os.chdir(cwd)
-    torch.manual_seed(1234)
-    enc = SmirkEncoder()
-    # random-init weights of the reference architecture (no checkpoint is obtainable offline); the shape head is zero-initialised
-    # by the reference (smirk_encoder.py:61-63) — give it a small std so FLAME sees non-trivial shape coefficients
-    with torch.no_grad():
-        enc.shape_encoder.shape_layers[0].weight.normal_(0, 1e-3)
-        enc.expression_encoder.expression_layers[0].weight.mul_(0.3)
-    gen = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
-    mods = [m.to(device).eval() for m in (enc, flame, rend, gen)]
-    return mods
-
-
-def cpu_baseline(sandbox, n_faces):
-    """The oracle (CPU port of the reference path) on `n_faces` frames; returns faces/s.  Checker code, timed beside the GPU."""
-    import numpy as np
-    from oracle import generator_ref as G, mobilenet_ref as M
-    from oracle.flame_ref import FlameRef
-    from oracle.render_ref import RendererRef
-    from smirk_amd import synth
-    nthr = min(os.cpu_count(), 32)          # more threads than this only thrash on a 4-16 frame sample
-    torch.set_num_threads(nthr)
-    os.environ["OMP_NUM_THREADS"] = str(nthr)
-    encr = M.SmirkEncoderRef().eval()
-    with torch.no_grad():
-        encr.shape_encoder.shape_layers[0].weight.normal_(0, 1e-3)
-    gsd = G.synth_state_dict(calibrate=False)
-    fr, rr = FlameRef(sandbox), RendererRef(sandbox)
-    img = synth.synth_images(n_faces, seed=5)
-    masked = synth.synth_generator_input(n_faces, seed=5)[:, 3:]
-
-    stages = {}
-
-    def run():
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            e = encr(img)
-        t1 = time.perf_counter()
-        p = {k: v.numpy() for k, v in e.items()}
-        p["cam"] = np.clip(p["cam"], [6, -.1, -.1], [10, .1, .1]).astype(np.float32)
-        fl = fr.forward(p)
-        t2 = time.perf_counter()
-        r = rr.forward(fl["vertices"], p["cam"])
-        t3 = time.perf_counter()
-        x = torch.cat([torch.from_numpy(r["rendered_img"]), masked], 1)
-        y = G.forward(gsd, x)
-        t4 = time.perf_counter()
-        stages.update(encode=t1 - t0, flame=t2 - t1, render=t3 - t2, generate=t4 - t3)
-        return y
-
-    run()                                   # warm-up (also builds raster_ref.c if needed)
-    t = time.perf_counter()
-    run()
-    dt = time.perf_counter() - t
-    return n_faces / dt, dt, nthr, {k: round(v, 3) for k, v in stages.items()}
-
-
-def main():
+# ------------------------------------------------------------------------------------------------------------------------------
+# launch plumbing
+# ------------------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--workload", choices=("full", "infer256", "flame512"), default="full")
+    ap.add_argument("--global-batch", type=int, default=None, help="frames per step over ALL GPUs (strong scaling; default 1024 / 256 / 512 by workload)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (weak scaling; overrides --global-batch)")
+    ap.add_argument("--micro-batch", type=int, default=MICRO_BATCH)
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
-                    help="run each batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
+                    help="run each micro-batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
-    ap.add_argument("--cpu-faces", type=int, default=96, help="sample size of the CPU baseline (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-faces", type=int, default=24, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--traffic", choices=("measure", "file", "off"), default=None,
+                    help="roofline.traffic: run two rocprofv3 --pmc passes of this script (default at 1 GPU), read profiles/pmc_traffic.json, or skip")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo stub of the path: tests/test_distributed_cpu.py
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)       # the run that rocprofv3 wraps (no JSON line, no baseline)
+    return ap.parse_args(argv)
 
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from smirk_amd import _lib as L, synth
-    from smirk_amd.pipeline import OutputGatherer, OverlappedPipeline, SmirkPipeline
-    sandbox = tempfile.mkdtemp(prefix=f"smirk_bench_r{rank}_")
-    enc, flame, rend, gen = build_modules(sandbox, dev)
-    from smirk_amd import masking as MK
-    cwd = os.getcwd(); os.chdir(sandbox)
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks under torch.distributed.run (one process per GPU)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dist_env():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# modules and inputs
+# ------------------------------------------------------------------------------------------------------------------------------
+def build_modules(sandbox, device, want=("enc", "flame", "rend", "gen")):
+    """Random-init weights of the reference architecture (no checkpoint is obtainable offline), He-initialised so that activations stay
+    O(1) through all 30+ layers (nn.Conv2d's default init shrinks them by ~2.4x per layer); every output is checked finite after warm-up."""
+    import torch
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, synth
+    synth.write_sandbox(sandbox)
+    cwd = os.getcwd()
+    os.chdir(sandbox)
     try:
-        face_prob = MK.load_probabilities_per_FLAME_triangle().to(dev)
+        flame = FLAME() if "flame" in want else None
+        rend = Renderer() if "rend" in want else None
     finally:
         os.chdir(cwd)
-    pipe = SmirkPipeline(enc, flame, rend, gen, face_probabilities=face_prob)
-    B = args.batch
-    img = synth.synth_images(B, seed=1000 + rank).to(dev)                  # resident in HBM before the timed region
-    masked = synth.synth_generator_input(B, seed=1000 + rank)[:, 3:].contiguous().to(dev)
-    # hull mask (1 = keep the photo, 0 = face region): a synthetic disc stands in for demo.py's mediapipe/cv2 convex hull (CPU preprocessing,
-    # out of scope); the masked image itself is then produced on the GPU by the masking utilities exactly as demo.py:138-165 does
-    hull = (synth.synth_generator_input(B, seed=1000 + rank)[:, 3:4] != 0).float().contiguous().to(dev)
-    kw = dict(masked_img=masked) if args.given_masked else dict(hull_mask=hull)
-    gather = OutputGatherer()
-    runner = OverlappedPipeline(pipe) if args.overlap else None
+    enc = gen = None
+    if "enc" in want:
+        enc = SmirkEncoder()
+        synth.he_init_(enc, seed=1234)
+        with torch.no_grad():
+            # the reference zero-initialises the shape head (smirk_encoder.py:61-63) — give it a small std so FLAME sees non-trivial shape
+            # coefficients; the pose/cam head keeps the reference initialisation (scale bias 7, smirk_encoder.py:26-31)
+            g = torch.Generator().manual_seed(99)
+            enc.shape_encoder.shape_layers[0].weight.copy_(torch.randn(enc.shape_encoder.shape_layers[0].weight.shape, generator=g) * 2e-2)
+            enc.expression_encoder.expression_layers[0].weight.copy_(
+                torch.randn(enc.expression_encoder.expression_layers[0].weight.shape, generator=g) * 3e-2)
+    if "gen" in want:
+        gen = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+        synth.he_init_(gen, seed=4321)
+    mods = [m.to(device).eval() if m is not None else None for m in (enc, flame, rend, gen)]
+    return mods
 
-    def finish(out):
-        gather.wait()                       # previous step's all-gather must have landed before its buffers are reused
-        gather.start(out)
 
-    def step():
-        """one batch of B frames enters the path; with --overlap its generator stage runs under the next batch's front stages
-        (independent batches, identical results) and completes in the next step() / in drain()."""
-        if runner is None:
-            finish(pipe(img, with_landmarks=True, **kw))
-        else:
-            done = runner.submit(img, **kw)
+def assert_finite(out, keys, where):
+    import torch
+    for k in keys:
+        if k in out and torch.is_tensor(out[k]) and out[k].is_floating_point():
+            if not bool(torch.isfinite(out[k]).all()):
+                raise SystemExit(f"bench.py: non-finite values in '{k}' ({where}) — the timed run would be measuring inf/NaN propagation")
+
+
+def output_stats(out):
+    s = {}
+    if "reconstructed_img" in out:
+        y = out["reconstructed_img"]
+        s["reconstructed_mean"], s["reconstructed_std"] = float(y.mean()), float(y.std())
+        s["reconstructed_saturated_frac"] = float(((y < 1e-4) | (y > 1 - 1e-4)).float().mean())
+    if "rendered_img" in out:
+        s["rendered_coverage"] = float((out["rendered_img"][:, 0] != 0).float().mean())
+    if "vertices" in out:
+        s["vertices_absmax"] = float(out["vertices"].abs().max())
+    return s
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = a port of the reference path; checker code, timed beside the GPU on a bounded sample)
+# ------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sandbox, workload, n_faces):
+    import numpy as np
+    import torch
+    from oracle import generator_ref as G, mobilenet_ref as M
+    from oracle.flame_ref import FlameRef
+    from oracle.render_ref import RendererRef
+    from smirk_amd import synth
+    nthr = min(os.cpu_count(), 32)          # more threads than this only thrash on a small sample
+    torch.set_num_threads(nthr)
+    os.environ["OMP_NUM_THREADS"] = str(nthr)
+    fr = FlameRef(sandbox)
+    stages = {}
+    if workload == "flame512":
+        p = synth.synth_flame_params(n_faces, seed=5)
+
+        def run():
+            t0 = time.perf_counter()
+            fr.forward(p)
+            stages["flame"] = time.perf_counter() - t0
+    else:
+        encr = M.SmirkEncoderRef().eval()
+        with torch.no_grad():
+            encr.shape_encoder.shape_layers[0].weight.normal_(0, 1e-3)
+        gsd = G.synth_state_dict(calibrate=False) if workload == "full" else None
+        rr = RendererRef(sandbox)
+        img = synth.synth_images(n_faces, seed=5)
+        masked = synth.synth_generator_input(n_faces, seed=5)[:, 3:]
+
+        def run():
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                e = encr(img)
+            t1 = time.perf_counter()
+            p = {k: v.numpy() for k, v in e.items()}
+            p["cam"] = np.clip(p["cam"], [6, -.1, -.1], [10, .1, .1]).astype(np.float32)
+            fl = fr.forward(p)
+            t2 = time.perf_counter()
+            r = rr.forward(fl["vertices"], p["cam"])
+            t3 = time.perf_counter()
+            stages.update(encode=t1 - t0, flame=t2 - t1, render=t3 - t2)
+            if gsd is not None:
+                G.forward(gsd, torch.cat([torch.from_numpy(r["rendered_img"]), masked], 1))
+                stages["generate"] = time.perf_counter() - t3
+
+    run(); run()                            # 2 warm-ups (the first also builds raster_ref.c if needed)
+    times, keep = [], {}
+    for _ in range(5):
+        t = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t)
+        keep = dict(stages) if times[-1] <= min(times) else keep
+    med = statistics.median(times)
+    what = {"full": "torch-CPU fp32 encoder + generator, numpy FLAME, C rasteriser with OpenMP", "infer256": "torch-CPU fp32 encoder, numpy FLAME, C rasteriser with OpenMP",
+            "flame512": "numpy FLAME"}[workload]
+    return {"value": n_faces / med, "unit": "faces/sec", "cores": nthr, "kind": "port", "host_cores": os.cpu_count(),
+            "stage_seconds": {k: round(v, 4) for k, v in keep.items()},
+            "sample": f"{n_faces} synthetic frames through the CPU oracle ({what}; {nthr} threads), 2 warm-ups + 5 timed passes, median {med:.2f} s "
+                      f"(min {min(times):.2f}, max {max(times):.2f})"}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# roofline helpers
+# ------------------------------------------------------------------------------------------------------------------------------
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "smirk_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_parse(db_dir, counter):
+    import sqlite3
+    dbs = glob.glob(os.path.join(db_dir, "**", "*.db"), recursive=True)
+    if not dbs:
+        raise RuntimeError(f"no rocpd database under {db_dir}")
+    c = sqlite3.connect(dbs[0])
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    agg = {}
+    for k, v in c.execute(f"select {name_col}, value from counters_collection where counter_name = ?", (counter,)):
+        k = k.split("(")[0].replace("void ", "").replace(", ", ",")
+        a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(v)
+    return agg
+
+
+def measure_traffic(args):
+    """Two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE — separate runs, kernel-trace only) over one step of this same workload.
+    Returns {kernel: bytes per launch} with the gfx950 correction (FETCH_SIZE counts 64 B per 128-B request: x2), or raises."""
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    inner = [sys.executable, os.path.abspath(__file__), "--pmc-inner", "--workload", args.workload, "--steps", "1", "--warmup", "1",
+             "--micro-batch", str(args.micro_batch), "--no-overlap"]
+    inner += ["--batch", str(min(args.micro_batch, per_rank_batch(args, 1)))] if args.workload == "full" else []
+    if args.given_masked:
+        inner.append("--given-masked")
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"smirk_pmc_{c}_", dir="/tmp")
+        r = subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", d, "-o", "p", "--"] + inner, cwd="/tmp", env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError(f"rocprofv3 --pmc {c} failed rc={r.returncode}: {r.stdout.decode(errors='replace')[-400:]}")
+        out[c] = pmc_parse(d, c)
+        shutil.rmtree(d, ignore_errors=True)
+    f, w = out["FETCH_SIZE"], out["WRITE_SIZE"]
+    table = {}
+    for k, (n, s) in f.items():
+        wn, ws = w.get(k, (1, 0.0))
+        table[k] = {"launches": n, "fetch_kb": s / n, "write_kb": ws / max(wn, 1), "bytes_per_launch": (2 * s / n + ws / max(wn, 1)) * 1024}
+    return table
+
+
+def per_rank_batch(args, world):
+    if args.batch is not None:
+        return args.batch
+    g = args.global_batch or {"full": 1024, "infer256": 256, "flame512": 512}[args.workload]
+    return max(1, g // world)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the workloads
+# ------------------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """step()/drain() + bookkeeping shared by the three workloads; `last` holds the most recent outputs of a micro-batch."""
+    keys = ()
+    last = None
+
+    def step(self):
+        raise NotImplementedError
+
+    def drain(self):
+        pass
+
+
+class FullWorkload(Workload):
+    keys = ("vertices", "rendered_img", "reconstructed_img", "cam", "expression_params")
+
+    def __init__(self, args, dev, rank, world, sandbox):
+        import torch
+        from smirk_amd import masking as MK, synth
+        from smirk_amd.pipeline import OutputGatherer, OverlappedPipeline, SmirkPipeline
+        enc, flame, rend, gen = build_modules(sandbox, dev)
+        self.gen = gen
+        cwd = os.getcwd(); os.chdir(sandbox)
+        try:
+            face_prob = MK.load_probabilities_per_FLAME_triangle().to(dev)
+        finally:
+            os.chdir(cwd)
+        self.pipe = SmirkPipeline(enc, flame, rend, gen, face_probabilities=face_prob)
+        self.B = per_rank_batch(args, world)
+        mb = min(args.micro_batch, self.B)
+        self.slices = [(i, min(i + mb, self.B)) for i in range(0, self.B, mb)]
+        if world > 1 and len({hi - lo for lo, hi in self.slices}) != 1:
+            raise SystemExit("multi-GPU all-gather needs equal micro-batches: choose a per-GPU batch that is a multiple of --micro-batch")
+        B = self.B
+        # a distinct seeded shard per rank, resident in HBM before the timed region; generated in chunks to bound host memory
+        self.img = torch.cat([synth.synth_images(hi - lo, seed=1000 + 97 * rank + lo).to(dev) for lo, hi in self.slices])
+        gi = [synth.synth_generator_input(hi - lo, seed=1000 + 97 * rank + lo) for lo, hi in self.slices]
+        self.masked = torch.cat([g[:, 3:].contiguous().to(dev) for g in gi])
+        # hull mask (1 = keep the photo, 0 = face region): a synthetic disc stands in for demo.py's mediapipe/cv2 convex hull (CPU
+        # preprocessing, out of scope); the masked image itself is produced on the GPU by the masking utilities as demo.py:138-165 does
+        self.hull = torch.cat([(g[:, 3:4] != 0).float().contiguous().to(dev) for g in gi])
+        assert self.img.shape[0] == B
+        self.given = args.given_masked
+        self.gather = OutputGatherer()
+        self.runner = OverlappedPipeline(self.pipe) if args.overlap else None
+
+    def _kw(self, lo, hi):
+        return dict(masked_img=self.masked[lo:hi]) if self.given else dict(hull_mask=self.hull[lo:hi])
+
+    def _finish(self, out):
+        self.gather.wait()                  # the previous micro-batch's all-gather must have landed before its buffers are reused
+        self.gather.start(out)
+        self.last = out
+
+    def step(self):
+        """the rank's whole shard enters the path, one micro-batch after the other; with overlap the generator stage of a micro-batch runs
+        under the front stages of the next one (independent frames, identical results) and completes in the next submit / in drain()."""
+        for lo, hi in self.slices:
+            if self.runner is None:
+                self._finish(self.pipe(self.img[lo:hi], with_landmarks=True, **self._kw(lo, hi)))
+            else:
+                done = self.runner.submit(self.img[lo:hi], **self._kw(lo, hi))
+                if done is not None:
+                    self._finish(done)
+
+    def drain(self):
+        if self.runner is not None:
+            done = self.runner.flush()
             if done is not None:
-                finish(done)
+                self._finish(done)
+        self.gather.wait()
 
-    def drain():
-        if runner is not None:
-            done = runner.flush()
-            if done is not None:
-                finish(done)
-        gather.wait()
+    def instrumented(self):
+        lo, hi = self.slices[0]
+        self._finish(self.pipe(self.img[lo:hi], with_landmarks=True, **self._kw(lo, hi)))
+        self.gather.wait()
+
+
+class InferWorkload(Workload):
+    keys = ("vertices", "rendered_img", "cam", "expression_params", "landmarks_fan")
+
+    def __init__(self, args, dev, rank, world, sandbox):
+        import torch
+        from smirk_amd import synth
+        from smirk_amd.pipeline import SmirkPipeline
+        enc, flame, rend, _ = build_modules(sandbox, dev, want=("enc", "flame", "rend"))
+        self.pipe = SmirkPipeline(enc, flame, rend, None)
+        self.B = per_rank_batch(args, world)
+        mb = min(args.micro_batch if args.micro_batch != MICRO_BATCH else 256, self.B)
+        self.slices = [(i, min(i + mb, self.B)) for i in range(0, self.B, mb)]
+        self.img = torch.cat([synth.synth_images(hi - lo, seed=2000 + 97 * rank + lo).to(dev) for lo, hi in self.slices])
+
+    def step(self):
+        for lo, hi in self.slices:
+            self.last = self.pipe(self.img[lo:hi], with_landmarks=True)
+
+    instrumented = step
+
+
+class FlameWorkload(Workload):
+    keys = ("vertices", "landmarks_fan", "landmarks_mp")
+
+    def __init__(self, args, dev, rank, world, sandbox):
+        import torch
+        from smirk_amd import synth
+        _, flame, _, _ = build_modules(sandbox, dev, want=("flame",))
+        self.flame = flame
+        self.B = per_rank_batch(args, world)
+        p = synth.synth_flame_params(self.B, seed=3000 + rank)
+        self.params = {k: torch.from_numpy(v).to(dev) for k, v in p.items()}
+
+    def step(self):
+        import torch
+        with torch.no_grad():
+            self.last = self.flame.forward(self.params)
+
+    instrumented = step
+
+
+class PlumbingWorkload(Workload):
+    """CPU/gloo stand-in for the path used ONLY by tests/test_distributed_cpu.py to drive this script's rank / shard / micro-batch /
+    gather / timing bookkeeping end to end without a GPU.  It computes nothing of SMIRK and its JSON line is labelled as such."""
+    keys = ("vertices", "rendered_img", "reconstructed_img")
+
+    def __init__(self, args, dev, rank, world, sandbox):
+        import torch
+        from smirk_amd.pipeline import OutputGatherer, shard_bounds
+        self.B = per_rank_batch(args, world)
+        self.lo, _ = shard_bounds(self.B * world, rank, world)
+        mb = min(args.micro_batch, self.B)
+        self.slices = [(i, min(i + mb, self.B)) for i in range(0, self.B, mb)]
+        self.ids = torch.arange(self.lo, self.lo + self.B, dtype=torch.float32)
+        self.gather = OutputGatherer()
+        self.seen = []
+
+    def step(self):
+        for lo, hi in self.slices:
+            v = self.ids[lo:hi]
+            out = {"vertices": v[:, None, None].expand(-1, 2, 3).contiguous(), "rendered_img": v[:, None, None, None].expand(-1, 1, 2, 2).contiguous(),
+                   "reconstructed_img": (v * 2)[:, None, None, None].expand(-1, 1, 2, 2).contiguous()}
+            self.gather.wait()
+            self.gather.start(out)
+            self.last = out
+            bufs = self.gather.wait()
+            self.seen.append(sorted(set(bufs["vertices"][:, 0, 0].tolist())))
+
+    def drain(self):
+        self.gather.wait()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def roofline_from_timer(timer, workload, traffic_table, traffic_source, dt_step):
+    per = {}
+    for name, flops, nbytes, e0, e1 in timer:
+        a = per.setdefault(name, [0.0, 0.0, 0.0, 0])
+        a[0] += flops or 0.0; a[1] += nbytes or 0.0; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
+    if not per:
+        return None
+    with_work = {k: v for k, v in per.items() if v[0] > 0 or v[1] > 0}
+    dom = max(with_work or per, key=lambda k: per[k][2])
+    fl, by, tm, n = per[dom]
+    split = ",true," in dom or dom.endswith("true>")
+    traffic = None
+    if traffic_table:
+        t = traffic_table.get(dom) or traffic_table.get(dom.replace(", ", ","))
+        traffic = (t["bytes_per_launch"] if isinstance(t, dict) else t) if t is not None else None
+    if fl > 0:
+        peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
+        roof = {"bound": "mfma", "kernel": dom, "achieved": fl / tm / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / tm / peak,
+                "traffic": traffic, "flop_per_launch": fl / n,
+                "mfma_issue_frac": (3.0 if split else 1.0) * fl / tm / peak,
+                "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per product "
+                         "(hi.hi, hi.lo, lo.hi), so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA") if split else
+                        "achieved = algorithmic flop per launch / HIP-event launch time; peak = f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
+    else:
+        roof = {"bound": "hbm", "kernel": dom, "achieved": by / tm / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by / tm / PEAK_HBM,
+                "traffic": traffic, "bytes_per_launch": by / n, "note": "achieved = algorithmic bytes per launch / HIP-event launch time"}
+    roof.update(launches_per_step=n, avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
+                kernel_name_source="reported by libsmirk_hip.so for the launch it made (smirk_conv_igemm_variant) / C entry point name",
+                kernels={k: {"ms_per_step": v[2] * 1e3, "launches": v[3], **({"tflops": v[0] / v[2] / 1e12} if v[0] > 0 else {}),
+                             **({"gbps": v[1] / v[2] / 1e9} if v[1] > 0 else {})} for k, v in sorted(per.items(), key=lambda t: -t[1][2])[:24]},
+                timed_share_of_step=sum(v[2] for v in per.values()) / dt_step if dt_step else None)
+    return roof
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    import torch
+    import torch.distributed as dist
+    rank, world, local = dist_env()
+    if args.plumbing_test:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(args.backend, **({"device_id": dev} if dev.type == "cuda" else {}))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or let bench.py launch itself)")
+    # every rank present and reachable over the collective backend (RCCL on GPUs): an actual all-gather of the rank ids
+    ranks_seen = 1
+    if world > 1:
+        ids = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks_seen = len(set(ids.tolist()))
+
+    from smirk_amd import _lib as L
+    sandbox = tempfile.mkdtemp(prefix=f"smirk_bench_r{rank}_")
+    cls = PlumbingWorkload if args.plumbing_test else {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload}[args.workload]
+    wl = cls(args, dev, rank, world, sandbox)
 
     def sync():
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    drain()
+        wl.step()
+    wl.drain()
     sync()
+    if wl.last is not None and not args.plumbing_test:
+        assert_finite(wl.last, wl.keys, "after warm-up")
+    if args.pmc_inner:                      # the pass rocprofv3 wraps: one more plain step, nothing else
+        for _ in range(args.steps):
+            wl.instrumented()
+        sync()
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step()
     t_host = time.perf_counter() - t0       # host time to ENQUEUE the K steps (launches are asynchronous)
-    drain()                                 # every one of the K batches is fully processed (and gathered) inside the timed region
+    wl.drain()                              # every frame of the K steps is fully processed (and gathered) inside the timed region
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    stats = {}
+    if wl.last is not None and not args.plumbing_test:
+        assert_finite(wl.last, wl.keys, "after the timed steps")
+        stats = output_stats(wl.last)
 
-    # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv_igemm launch --------
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline and not args.plumbing_test:
+        # ---- one extra instrumented pass of a micro-batch: HIP events around every library launch, on the launch stream -------------
         L.TIMER = []
-        finish(pipe(img, with_landmarks=True, **kw)); gather.wait(); torch.cuda.synchronize()
-        per = {}
-        for name, flops, e0, e1 in L.TIMER:
-            a = per.setdefault(name, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
-        L.TIMER = None
-        dom = max(per, key=lambda k: per[k][1])
-        fl, tm, n = per[dom]
-        split = ",true," in dom or dom.endswith("true>")
-        traffic = None                          # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes
-        try:
-            traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(dom)
-        except Exception:
-            pass
-        peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
-        roof = {"bound": "mfma", "kernel": dom, "achieved": fl / tm / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": fl / tm / peak, "traffic": traffic, "launches_per_step": n,
-                "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc in separate passes (profiles/r01d_pmc_hbm.txt); "
-                                "includes Infinity-Cache hits; algorithmic operand bytes per launch = activations in + out + weights",
-                "mfma_issue_frac": (3.0 if split else 1.0) * fl / tm / peak,
-                "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per "
-                         "product (hi.hi, hi.lo, lo.hi) so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA") if split
-                else "achieved = algorithmic 2*M*N*K flop per launch / HIP-event launch time; peak = f32-input MFMA",
-                "avg_launch_ms": tm / n * 1e3, "flop_per_launch": fl / n,
-                "all_igemm": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]} for k, v in per.items()},
-                "igemm_share_of_step": sum(v[1] for v in per.values()) / (dt / args.steps)}
+        wl.instrumented(); wl.drain(); torch.cuda.synchronize()
+        timer, L.TIMER = L.TIMER, None
+        mode = args.traffic or ("measure" if world == 1 else "file")
+        table, src = None, "not collected"
+        if mode == "measure":
+            try:
+                table = measure_traffic(args)
+                src = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes, --kernel-trace only) over one step; "
+                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; Infinity-Cache hits included)")
+                try:
+                    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+                    json.dump({"kernel_sources_sha": kernel_sources_sha(), "workload": args.workload, "kernels": table},
+                              open(os.path.join(REPO, "gpurun_out", f"pmc_traffic_{args.workload}.json"), "w"), indent=1)
+                except OSError:
+                    pass
+            except Exception as e:          # noqa: BLE001 — the bench line must still be produced
+                src = f"rocprofv3 pass failed ({type(e).__name__}: {str(e)[:200]})"
+                mode = "file"
+        if table is None and mode == "file":
+            try:
+                j = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+                if j.get("kernel_sources_sha") == kernel_sources_sha() and j.get("workload", "full") == args.workload:
+                    table, src = j["kernels"], src + "; profiles/pmc_traffic.json (same kernel sources, sha " + j["kernel_sources_sha"] + ")"
+                else:
+                    src += "; profiles/pmc_traffic.json was measured on different kernel sources / workload -> traffic withheld (null)"
+            except Exception:               # noqa: BLE001
+                src += "; no profiles/pmc_traffic.json"
+        roof = roofline_from_timer(timer, args.workload, table, src, dt / args.steps / max(1, len(getattr(wl, "slices", [0]))))
 
     if rank == 0:
+        B = wl.B
         faces = B * world * args.steps
         value = faces / dt
         cpu = None
-        if world == 1 and args.cpu_faces > 0:
-            v, cdt, nthr, stages = cpu_baseline(sandbox, args.cpu_faces)
-            cpu = {"value": v, "unit": "faces/sec", "cores": nthr, "kind": "port", "host_cores": os.cpu_count(),
-                   "stage_seconds": stages,
-                   "sample": f"{args.cpu_faces} synthetic 224x224 frames through the CPU oracle (torch-CPU fp32 encoder+generator, numpy "
-                             f"FLAME, C rasteriser with OpenMP; {nthr} threads), 1 warm-up + 1 timed pass = {cdt:.1f} s"}
-        print(json.dumps({
-            "metric": "faces/sec (encode+FLAME+render+generate) @224x224", "value": value, "unit": "faces/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 results; generator convs as split-fp16 x3 MFMA with f32 accumulate (fp32-class error), rest f32" if gen.precision == "f16x3" else "f32",
+        if world == 1 and args.cpu_faces > 0 and not args.plumbing_test:
+            cpu = cpu_baseline(sandbox, args.workload, args.cpu_faces if args.workload != "flame512" else 512)
+        weak = args.batch is not None
+        flop_face = {"full": FLOP_PER_FACE, "infer256": FLOP_PER_FACE_INFER, "flame512": FLOP_PER_FACE_FLAME}[args.workload]
+        gen_prec = getattr(getattr(wl, "gen", None), "precision", None)
+        line = {
+            "metric": METRIC[args.workload] if not args.plumbing_test else "PLUMBING TEST (CPU stub of the path; not a measurement)",
+            "value": value, "unit": "faces/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+            "dtype": ("f32 results; encoder + generator convs as split-fp16 x3 MFMA with f32 accumulate (fp32-class error), FLAME / raster f32"
+                      if gen_prec == "f16x3" or args.workload == "infer256" else "f32"),
             "data": "synthetic",
-            "config": {"workload": "full inference incl. SmirkGenerator re-synthesis (BASELINE config 4: 1024 frames / 8 GPUs)",
-                       "frames_per_gpu": B, "global_batch": B * world, "image": "224x224", "parallelism": f"dp{world}",
-                       "collective": "async all_gather(vertices, rendered_img, reconstructed_img)" if world > 1 else "none (1 GPU)",
-                       "weights": "random-init reference architecture (no checkpoint offline)",
-                       "masking": "given masked image" if args.given_masked else "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",
-                       "schedule": "2-stream software pipeline: generator(batch i) || encode+FLAME+render(batch i+1)" if args.overlap else "serial stages"},
+            "config": {"workload": {"full": "BASELINE config 4: full inference incl. SmirkGenerator re-synthesis, 1024-frame batch sharded over the GPUs",
+                                    "infer256": "BASELINE config 3: full inference (encoder + FLAME + renderer), batch 256",
+                                    "flame512": "BASELINE config 2: FLAME-only, batch 512 random (shape, exp, pose, jaw, eyelid) -> 5023 vertices"}[args.workload],
+                       "frames_per_gpu_per_step": B, "global_batch": B * world, "micro_batch": min(args.micro_batch, B), "image": "224x224",
+                       "parallelism": f"dp{world}", "rccl_ranks_seen": ranks_seen,
+                       "collective": ("async all_gather_into_tensor(vertices, rendered_img, reconstructed_img) per micro-batch" if world > 1 else "none (1 GPU)")
+                       if args.workload == "full" or args.plumbing_test else "none (outputs stay on the rank)",
+                       "weights": "random-init (He) reference architecture, no checkpoint offline; outputs asserted finite",
+                       **({"masking": "given masked image" if args.given_masked else
+                           "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",
+                           "schedule": "2-stream software pipeline: generator(micro-batch i) || encode+FLAME+render(micro-batch i+1)" if args.overlap else "serial stages"}
+                          if args.workload == "full" else {})},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
-            "path_tflops_per_gpu": value / world * FLOP_PER_FACE / 1e12,
-            "path_frac_of_fp32_mfma_peak": value / world * FLOP_PER_FACE / PEAK_FP32_MFMA,
-            "path_frac_of_f16_mfma_peak": value / world * FLOP_PER_FACE / PEAK_F16_MFMA,
-            "roofline": roof, "cpu_baseline": cpu}))
+            "path_tflops_per_gpu": value / world * flop_face / 1e12,
+            "path_frac_of_f16_mfma_peak": value / world * flop_face / PEAK_F16_MFMA,
+            "output_stats": stats, "roofline": roof, "cpu_baseline": cpu}
+        if args.plumbing_test:
+            line["plumbing"] = {"gathered_ids_last": wl.seen[-1], "micro_batches_per_step": len(wl.slices), "gathers": len(wl.seen)}
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -5,8 +5,8 @@ numpy float32 restatement of the reference FLAME layer:
   src/FLAME/lbs.py:26-32 (rot_mat_to_euler), :101-137 (vertices2landmarks), :140-227 (lbs),
                    :230-271 (vertices2joints, blend_shapes), :274-305 (batch_rodrigues),
                    :308-378 (transform_mat, batch_rigid_transform)
-Pinned against the real reference classes by tests/test_oracle_pinning.py (build container) and by
-tests/golden/flame_golden.npz (everywhere).
+Pinned against the real reference classes: oracle/make_golden.py runs them (build container) and commits their outputs as
+tests/golden/flame_golden.npz; tests/test_cpu_suite.py::test_flame_oracle_vs_reference_golden compares this restatement with them everywhere.
 """
 import os
 import pickle

@@ -3,7 +3,8 @@
 torch-CPU fp32 functional restatement of src/smirk_generator.py (SmirkGenerator.forward :51-86,
 _block :88-119, ResnetBlock :121-178) driven by a reference-keyed state_dict, eval-mode BatchNorm.
 Floating-point kernel => a torch fp32 reference is the oracle (tolerances are stated in the tests).
-Pinned against the reference class itself by tests/test_oracle_pinning.py and tests/golden/generator_golden.npz.
+Pinned against the reference class itself: oracle/make_golden.py runs it (build container) -> tests/golden/generator_golden.npz,
+compared with this restatement by tests/test_cpu_suite.py::test_generator_oracle_vs_reference_golden.
 """
 import torch
 import torch.nn.functional as F

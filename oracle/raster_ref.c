@@ -10,7 +10,7 @@
  *   csrc/utils/geometry_utils.h                     :: EdgeFunctionForward, BarycentricCoordinatesForward (kEpsilon = 1e-8)
  *   csrc/rasterize_meshes/rasterization_utils.h     :: PixToNonSquareNdc
  * PARITY UNPINNED: the reference has no golden vectors for this call; correctness is defended by the analytic
- * known-answer tests in tests/test_oracle_raster.py.
+ * known-answer tests in tests/test_cpu_suite.py (test_raster_kat_*, test_raster_c_matches_numpy_on_random_soup) and tests/test_raster_differential.py.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (plain fp32 mul/sub/add/div, no FMA: the x86 wheel has none).
  */

@@ -117,7 +117,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.smirk_abi_version() != ABI_VERSION:
             raise SmirkHipError("libsmirk_hip.so ABI version mismatch; rebuild")
-        _LIB = L
+        _LIB = _TimedLib(L)
     return _LIB
 
 
@@ -152,19 +152,40 @@ def as_f32c(t):
     return t.contiguous()
 
 
-# bench.py sets TIMER to a list to collect per-launch (kernel, algorithmic flop, start, end) HIP events on the launch stream
+# bench.py sets TIMER to a list to collect per-launch (kernel, algorithmic flop, algorithmic bytes, start, end) HIP events on the launch stream
 TIMER = None
+_IN_TIMED = False
 
 
-def timed(kernel, flops, fn):
-    if TIMER is None:
+def timed(kernel, flops, fn, nbytes=None):
+    """Bracket one library launch with HIP events on the current (= launch) stream when bench.py has armed TIMER."""
+    global _IN_TIMED
+    if TIMER is None or _IN_TIMED:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = fn()
-    e1.record()
-    TIMER.append((kernel, flops, e0, e1))
+    _IN_TIMED = True
+    try:
+        e0.record()
+        r = fn()
+        e1.record()
+    finally:
+        _IN_TIMED = False
+    TIMER.append((kernel, flops, nbytes, e0, e1))
     return r
+
+
+class _TimedLib:
+    """Attribute proxy over the CDLL: with TIMER armed, every entry point that enqueues work is timed under its own name (launches that a
+    caller already wrapped in timed() keep the caller's more specific label)."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if TIMER is None or _IN_TIMED or name.endswith("_bytes") or name in ("smirk_strerror", "smirk_abi_version", "smirk_mbconv_supported"):
+            return fn
+        return lambda *a: timed(name, None, lambda: fn(*a))
 
 
 def igemm_kernel_name(n_gemm, split=False, c0=32, c1=0, k=3):

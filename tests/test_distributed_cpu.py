@@ -52,3 +52,31 @@ def test_output_gather_gloo_world2():
     res = sorted(q.get(timeout=120) for _ in procs)
     [p.join(60) for p in procs]
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_self_launch_world2_gloo_plumbing():
+    """`python bench.py --gpus 2` launches itself as two ranks (torch.distributed.run on 127.0.0.1) and drives its rank / shard / micro-batch /
+    all-gather / max-over-ranks bookkeeping end to end — here on CPU with gloo and a stub of the path (`--plumbing-test`), the same code
+    the GPU run executes around the real pipeline."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", "gloo", "--plumbing-test", "--steps", "3",
+                        "--warmup", "1", "--global-batch", "24", "--micro-batch", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, cwd=repo)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["rccl_ranks_seen"] == 2 and j["config"]["global_batch"] == 24
+    assert j["config"]["frames_per_gpu_per_step"] == 12 and j["scaling"] == "strong" and j["steps"] == 3
+    p = j["plumbing"]
+    assert p["micro_batches_per_step"] == 3 and p["gathers"] == 3 * 4
+    assert p["gathered_ids_last"] == [8.0, 9.0, 10.0, 11.0, 20.0, 21.0, 22.0, 23.0]      # last micro-batch of rank 0 and of rank 1
+    assert abs(j["value"] - 24 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    # a launcher-provided WORLD_SIZE that contradicts --gpus is refused instead of silently mis-reporting
+    r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--plumbing-test"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, cwd=repo)
+    assert r2.returncode != 0 and b"WORLD_SIZE=1" in r2.stderr
