@@ -15,8 +15,9 @@ Workloads (BASELINE.json configs):
   flame512  config 2 — FLAME only, 512 random parameter vectors -> 5023 vertices.
 One "step" = one pass of the workload over its batch, inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-`roofline`: every kernel launch of one extra instrumented step is bracketed by HIP events on its launch stream inside libsmirk_hip.so /
-the ctypes layer; the dominant kernel's ALGORITHMIC flop (2*M*N*K) per launch / its mean launch time is `achieved`.  `traffic` comes from
+`roofline`: every kernel launch of one extra instrumented pass is bracketed by HIP events on its launch stream by libsmirk_hip.so's own
+launch profiler, which also reports the kernel instantiation it launched and the launch's algorithmic flop / bytes; the dominant kernel's
+ALGORITHMIC flop (2*M*N*K) per launch / its mean launch time is `achieved`.  `traffic` comes from
 two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) that this script starts on itself (`--traffic measure`, the default
 on one GPU), corrected as MI355X_MICROARCH.md prescribes for gfx950 (2*FETCH_SIZE + WRITE_SIZE, KiB units).
 `cpu_baseline`: the CPU oracle (a port of the reference path) timed on this box's host cores on a bounded sample — checker code,
@@ -109,17 +110,14 @@ def build_modules(sandbox, device, want=("enc", "flame", "rend", "gen")):
     if "enc" in want:
         enc = SmirkEncoder()
         synth.he_init_(enc, seed=1234)
-        with torch.no_grad():
-            # the reference zero-initialises the shape head (smirk_encoder.py:61-63) — give it a small std so FLAME sees non-trivial shape
-            # coefficients; the pose/cam head keeps the reference initialisation (scale bias 7, smirk_encoder.py:26-31)
-            g = torch.Generator().manual_seed(99)
-            enc.shape_encoder.shape_layers[0].weight.copy_(torch.randn(enc.shape_encoder.shape_layers[0].weight.shape, generator=g) * 2e-2)
-            enc.expression_encoder.expression_layers[0].weight.copy_(
-                torch.randn(enc.expression_encoder.expression_layers[0].weight.shape, generator=g) * 3e-2)
     if "gen" in want:
         gen = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
         synth.he_init_(gen, seed=4321)
     mods = [m.to(device).eval() if m is not None else None for m in (enc, flame, rend, gen)]
+    if enc is not None:
+        # the heads are rescaled on the features the random backbones actually produce, so that pose / camera / shape / expression land in
+        # the ranges of the trained network (the reference's own head init — zero shape head, 1e-3 pose head — assumes trained-scale features)
+        synth.calibrate_encoder_heads_(mods[0], device)
     return mods
 
 
@@ -141,6 +139,7 @@ def output_stats(out):
         s["rendered_coverage"] = float((out["rendered_img"][:, 0] != 0).float().mean())
     if "vertices" in out:
         s["vertices_absmax"] = float(out["vertices"].abs().max())
+        s["mesh_sane"] = bool(s["vertices_absmax"] < 1.0)          # the head template spans about +-0.15; a random encoder could blow it up
     return s
 
 
@@ -420,37 +419,40 @@ class PlumbingWorkload(Workload):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-def roofline_from_timer(timer, workload, traffic_table, traffic_source, dt_step):
+def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass):
+    """recs: [(kernel, flop, bytes, ms)] from the library's launch profiler over ONE instrumented pass of a micro-batch."""
     per = {}
-    for name, flops, nbytes, e0, e1 in timer:
+    for name, flops, nbytes, ms in recs:
         a = per.setdefault(name, [0.0, 0.0, 0.0, 0])
-        a[0] += flops or 0.0; a[1] += nbytes or 0.0; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
+        a[0] += flops; a[1] += nbytes; a[2] += ms * 1e-3; a[3] += 1
     if not per:
         return None
-    with_work = {k: v for k, v in per.items() if v[0] > 0 or v[1] > 0}
-    dom = max(with_work or per, key=lambda k: per[k][2])
+    dom = max(per, key=lambda k: per[k][2])
     fl, by, tm, n = per[dom]
     split = ",true," in dom or dom.endswith("true>")
+    gemm = dom.startswith(("conv_igemm_kernel", "flame_blend_skin", "flame_bwd"))
     traffic = None
     if traffic_table:
         t = traffic_table.get(dom) or traffic_table.get(dom.replace(", ", ","))
         traffic = (t["bytes_per_launch"] if isinstance(t, dict) else t) if t is not None else None
-    if fl > 0:
+    if gemm and fl > 0:
         peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
         roof = {"bound": "mfma", "kernel": dom, "achieved": fl / tm / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / tm / peak,
-                "traffic": traffic, "flop_per_launch": fl / n,
+                "traffic": traffic, "flop_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n if by else None,
                 "mfma_issue_frac": (3.0 if split else 1.0) * fl / tm / peak,
                 "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per product "
                          "(hi.hi, hi.lo, lo.hi), so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA") if split else
                         "achieved = algorithmic flop per launch / HIP-event launch time; peak = f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
     else:
         roof = {"bound": "hbm", "kernel": dom, "achieved": by / tm / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by / tm / PEAK_HBM,
-                "traffic": traffic, "bytes_per_launch": by / n, "note": "achieved = algorithmic bytes per launch / HIP-event launch time"}
-    roof.update(launches_per_step=n, avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
-                kernel_name_source="reported by libsmirk_hip.so for the launch it made (smirk_conv_igemm_variant) / C entry point name",
-                kernels={k: {"ms_per_step": v[2] * 1e3, "launches": v[3], **({"tflops": v[0] / v[2] / 1e12} if v[0] > 0 else {}),
-                             **({"gbps": v[1] / v[2] / 1e9} if v[1] > 0 else {})} for k, v in sorted(per.items(), key=lambda t: -t[1][2])[:24]},
-                timed_share_of_step=sum(v[2] for v in per.values()) / dt_step if dt_step else None)
+                "traffic": traffic, "bytes_per_launch": by / n,
+                "note": "achieved = algorithmic bytes (unique operands in + out) per launch / HIP-event launch time" if by else
+                        "the dispatcher states no algorithmic byte count for this kernel"}
+    roof.update(launches_per_pass=n, avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
+                kernel_name_source="libsmirk_hip.so launch profiler (smirk_profile_start/stop): the instantiation that was launched, HIP events on its launch stream",
+                kernels={k: {"ms_per_pass": round(v[2] * 1e3, 4), "launches": v[3], **({"tflops": round(v[0] / v[2] / 1e12, 2)} if v[0] > 0 else {}),
+                             **({"gbps": round(v[1] / v[2] / 1e9, 1)} if v[1] > 0 else {})} for k, v in sorted(per.items(), key=lambda t: -t[1][2])[:28]},
+                profiled_kernel_ms_per_pass=sum(v[2] for v in per.values()) * 1e3, wall_ms_per_pass=dt_pass * 1e3)
     return roof
 
 
@@ -522,9 +524,9 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline and not args.plumbing_test:
         # ---- one extra instrumented pass of a micro-batch: HIP events around every library launch, on the launch stream -------------
-        L.TIMER = []
+        L.profile_start()
         wl.instrumented(); wl.drain(); torch.cuda.synchronize()
-        timer, L.TIMER = L.TIMER, None
+        recs = L.profile_stop()
         mode = args.traffic or ("measure" if world == 1 else "file")
         table, src = None, "not collected"
         if mode == "measure":
@@ -550,7 +552,7 @@ def main():
                     src += "; profiles/pmc_traffic.json was measured on different kernel sources / workload -> traffic withheld (null)"
             except Exception:               # noqa: BLE001
                 src += "; no profiles/pmc_traffic.json"
-        roof = roofline_from_timer(timer, args.workload, table, src, dt / args.steps / max(1, len(getattr(wl, "slices", [0]))))
+        roof = roofline_from_records(recs, args.workload, table, src, dt / args.steps / max(1, len(getattr(wl, "slices", [0]))))
 
     if rank == 0:
         B = wl.B
@@ -576,7 +578,7 @@ def main():
                        "parallelism": f"dp{world}", "rccl_ranks_seen": ranks_seen,
                        "collective": ("async all_gather_into_tensor(vertices, rendered_img, reconstructed_img) per micro-batch" if world > 1 else "none (1 GPU)")
                        if args.workload == "full" or args.plumbing_test else "none (outputs stay on the rank)",
-                       "weights": "random-init (He) reference architecture, no checkpoint offline; outputs asserted finite",
+                       "weights": "random-init (He) reference architecture, encoder heads rescaled to the trained network's parameter ranges; no checkpoint offline; outputs asserted finite",
                        **({"masking": "given masked image" if args.given_masked else
                            "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",
                            "schedule": "2-stream software pipeline: generator(micro-batch i) || encode+FLAME+render(micro-batch i+1)" if args.overlap else "serial stages"}

@@ -287,6 +287,89 @@ int smirk_mbconv_fused_split16(const void* x, const void* wexp, const float* s1,
                                int B, int H, int W, int Cin, int mid, int Cout, int stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Whole-network entries (SURVEY.md §8(b) proposal): ONE call enqueues every layer of a module's forward on `stream`, so a host in any
+ * language drives the path with a handful of calls instead of re-implementing the ~100-launch layer schedules.  All weights are passed
+ * in the PACKED form the per-layer entries above take (the Python host packs them once per parameter version); activations live in the
+ * caller-provided workspace.  Same conventions as everything else: no allocation, no synchronisation, 0 / negative error code.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct SmirkConvLayer {
+    const void* w;       /* packed weight: [N][K] (K = (ky,kx,c)), fp32 or split16 rows as the precision says; depthwise: [9][C] fp32 */
+    const float* scale;  /* [Cout] folded eval-mode BatchNorm scale (NULL = 1)                                                        */
+    const float* shift;  /* [Cout] folded BatchNorm shift, or the conv bias (ConvTranspose2d)                                          */
+} SmirkConvLayer;
+
+#define SMIRK_GEN_MAX_RES 16
+enum { SMIRK_PRECISION_F32 = 0, SMIRK_PRECISION_F16X3 = 1 };
+
+/* SmirkGenerator(in_channels, out_channels, init_features, res_blocks) — src/smirk_generator.py:8-49 (parameter inventory), :51-86 (forward). */
+typedef struct SmirkGeneratorWeights {
+    int32_t in_channels, out_channels, features, res_blocks;
+    int32_t precision;   /* SMIRK_PRECISION_*                                                                                  */
+    int32_t cin_pad;     /* channels of the packed network input (8 in f16x3 mode; in_channels rounded up to 4 in f32 mode)    */
+    SmirkConvLayer enc[5][2];                  /* encoder1..4, bottleneck: conv1+norm1, conv2+norm2        (:13-27, _block :88-119) */
+    SmirkConvLayer res[SMIRK_GEN_MAX_RES][2];  /* resnet_blocks[k].conv_block.{1,2} and .{5,6}            (:29-32, :121-178)       */
+    SmirkConvLayer up[4];                      /* upconv4, 3, 2, 1: w = [(dy,dx,co)][ci], shift = bias     (:34-45)                 */
+    SmirkConvLayer dec[4][2];                  /* decoder4, 3, 2, 1                                                                 */
+    const float* final_w;                      /* conv.weight [out_channels][features] fp32                (:47-49)                 */
+    const float* final_b;                      /* conv.bias [out_channels]                                                          */
+} SmirkGeneratorWeights;
+
+size_t smirk_generator_workspace_bytes(const SmirkGeneratorWeights* w /*host struct*/, int B, int H, int W);
+/* y[B][out_channels][H][W] = SmirkGenerator.forward(cat(a, b)) — a[B][Ca][H][W] and b[B][Cb][H][W] are NCHW fp32, Ca + Cb == in_channels
+ * (b may be NULL with Cb == 0: the caller already concatenated, smirk_trainer.py:94 / demo.py:167 `torch.cat([rendered_img, masked_img], 1)`).
+ * H, W multiples of 16 (4 pooling levels).  taps (nullable): 10 device pointers that receive the intermediate activations
+ * enc1..enc4, bottleneck, res, dec4..dec1 in the precision's storage format (parity tests); passing taps disables the fused tail. */
+int smirk_generator_forward(const SmirkGeneratorWeights* w, const float* a, int Ca, const float* b, int Cb, float* y,
+                            int B, int H, int W, void* const* taps, void* ws, size_t ws_bytes, void* stream);
+
+/* One timm MobileNetV3-"minimal" block.  kind 0 = DepthwiseSeparable (dw -> pw), 1 = InvertedResidual (pw -> dw -> pwl),
+ * 2 = ConvBnAct 1x1 (pw only). */
+typedef struct SmirkMbBlock {
+    int32_t kind, stride, cin, mid, cout, skip;
+    SmirkConvLayer pw, dw, pwl;
+} SmirkMbBlock;
+
+#define SMIRK_BACKBONE_MAX_BLOCKS 24
+/* One sub-encoder of SmirkEncoder: backbone (features[-1]) -> global average pool -> Linear (+ the ExpressionEncoder clamps)
+ * — src/smirk_encoder.py:14-45 (PoseEncoder), :48-73 (ShapeEncoder), :76-110 (ExpressionEncoder). */
+typedef struct SmirkBackboneWeights {
+    int32_t n_blocks, precision, n_out;
+    int32_t clamp_n_exp;        /* >= 0: apply smirk_expression_clamps with this n_exp to the head output (smirk_encoder.py:104-108); -1: none */
+    int32_t stem_cout, feat_ch; /* 16; channels of the last feature map (576 / 960)                                                  */
+    SmirkConvLayer stem;        /* conv_stem [Cout][27] fp32 + bn1                                                                    */
+    SmirkMbBlock blocks[SMIRK_BACKBONE_MAX_BLOCKS];
+    const float* head_w;        /* Linear weight [n_out][feat_ch]                                                                     */
+    const float* head_b;        /* [n_out]                                                                                            */
+} SmirkBackboneWeights;
+
+size_t smirk_backbone_workspace_bytes(const SmirkBackboneWeights* w /*host struct*/, int B, int H, int W);
+/* img[B][3][H][W] NCHW in [0,1] -> out[B][n_out] fp32 (n_out == 0: no head, out may be NULL and feat_out is required).
+ * feat_out (nullable): the last feature map, NHWC [B][ceil(H/32)][ceil(W/32)][feat_ch], in the precision's storage format (parity tests).  The three sub-encoders of SmirkEncoder.forward (smirk_encoder.py:123-133) are independent: call this entry once
+ * per sub-encoder, each on its own stream and workspace, to let their small launches interleave. */
+int smirk_backbone_forward(const SmirkBackboneWeights* w, const float* img, int B, int H, int W, float* out, void* feat_out,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Launch profiler (diagnostics; the one place where the library creates HIP events and synchronises — on request only).
+ * Between smirk_profile_start() and smirk_profile_stop() every kernel the library launches from the calling process is bracketed
+ * by a pair of hipEvents on ITS launch stream.  stop() waits for them and reports, per launch, the kernel's name as instantiated,
+ * its algorithmic flop / bytes where the dispatcher knows them (0 otherwise) and its duration.  bench.py builds `roofline` from this.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct SmirkProfileRecord {
+    char kernel[120];
+    double flop;      /* algorithmic floating-point operations of the launch (2*M*N*K for the GEMM-shaped kernels), 0 if not stated */
+    double bytes;     /* algorithmic bytes (unique operands in + out) for the bandwidth-bound kernels, 0 if not stated             */
+    float ms;         /* hipEventElapsedTime between the events recorded before and after the launch, on the launch stream          */
+    int32_t _pad;
+} SmirkProfileRecord;
+int smirk_profile_start(void);
+/* returns the number of launches recorded (may exceed cap; only the first `cap` are written), or a negative error */
+int smirk_profile_stop(SmirkProfileRecord* out, int cap);
+/* per-image random point budgets of demo.py:154-156 computed on the device (no host round trip):
+ * rbound[b] = (int64)(n_points * (1 / mul) * rscale^rsing), rsing in {-1, +1}, rscale ~ U[1, mul) — Philox keyed by (seed, offset). */
+int smirk_random_point_budget(int64_t* rbound, int B, int n_points, float mul, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Video loop pre/post-processing — replaces the cv2 / skimage calls of demo_video.py:107-214 so that a batch
  * of decoded frames stays in HBM from uint8 in to uint8 out.  uint8 images are HWC (cv2 layout), float images NCHW in [0,1].
  * ------------------------------------------------------------------------------------------------------------------ */

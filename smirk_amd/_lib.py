@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = C.c_void_p
 _i = C.c_int
@@ -34,6 +34,34 @@ class SmirkRenderMesh(C.Structure):
 class SmirkConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C0", "C1", "Cout", "KH", "KW", "stride", "pad_t", "pad_l",
                                          "Ho", "Wo", "pad_mode", "act", "out_mode")]
+
+
+class SmirkConvLayer(C.Structure):
+    _fields_ = [("w", _p), ("scale", _p), ("shift", _p)]
+
+
+GEN_MAX_RES, BACKBONE_MAX_BLOCKS = 16, 24
+PRECISION_F32, PRECISION_F16X3 = 0, 1
+
+
+class SmirkGeneratorWeights(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "out_channels", "features", "res_blocks", "precision", "cin_pad")] + \
+               [("enc", SmirkConvLayer * 2 * 5), ("res", SmirkConvLayer * 2 * GEN_MAX_RES), ("up", SmirkConvLayer * 4),
+                ("dec", SmirkConvLayer * 2 * 4), ("final_w", _p), ("final_b", _p)]
+
+
+class SmirkMbBlock(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "stride", "cin", "mid", "cout", "skip")] + \
+               [("pw", SmirkConvLayer), ("dw", SmirkConvLayer), ("pwl", SmirkConvLayer)]
+
+
+class SmirkBackboneWeights(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_blocks", "precision", "n_out", "clamp_n_exp", "stem_cout", "feat_ch")] + \
+               [("stem", SmirkConvLayer), ("blocks", SmirkMbBlock * BACKBONE_MAX_BLOCKS), ("head_w", _p), ("head_b", _p)]
+
+
+class SmirkProfileRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 120), ("flop", C.c_double), ("bytes", C.c_double), ("ms", C.c_float), ("_pad", C.c_int32)]
 
 
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -94,6 +122,13 @@ _SIGS = {
     "smirk_dwconv3x3_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "smirk_gap_linear_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_expression_clamps": (_i, [_p, _i, _i, _p]),
+    "smirk_generator_workspace_bytes": (_sz, [C.POINTER(SmirkGeneratorWeights), _i, _i, _i]),
+    "smirk_generator_forward": (_i, [C.POINTER(SmirkGeneratorWeights), _p, _i, _p, _i, _p, _i, _i, _i, C.POINTER(_p), _p, _sz, _p]),
+    "smirk_backbone_workspace_bytes": (_sz, [C.POINTER(SmirkBackboneWeights), _i, _i, _i]),
+    "smirk_backbone_forward": (_i, [C.POINTER(SmirkBackboneWeights), _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "smirk_profile_start": (_i, []),
+    "smirk_profile_stop": (_i, [C.POINTER(SmirkProfileRecord), _i]),
+    "smirk_random_point_budget": (_i, [_p, _i, _i, C.c_float, C.c_uint64, C.c_uint64, _p]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -117,7 +152,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.smirk_abi_version() != ABI_VERSION:
             raise SmirkHipError("libsmirk_hip.so ABI version mismatch; rebuild")
-        _LIB = _TimedLib(L)
+        _LIB = L
     return _LIB
 
 
@@ -152,62 +187,62 @@ def as_f32c(t):
     return t.contiguous()
 
 
-# bench.py sets TIMER to a list to collect per-launch (kernel, algorithmic flop, algorithmic bytes, start, end) HIP events on the launch stream
-TIMER = None
-_IN_TIMED = False
+def profile_start():
+    """Arm the library's launch profiler (include/smirk_hip.h): every kernel it launches from now on is bracketed by HIP events on its stream."""
+    check(lib().smirk_profile_start())
 
 
-def timed(kernel, flops, fn, nbytes=None):
-    """Bracket one library launch with HIP events on the current (= launch) stream when bench.py has armed TIMER."""
-    global _IN_TIMED
-    if TIMER is None or _IN_TIMED:
-        return fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    _IN_TIMED = True
-    try:
-        e0.record()
-        r = fn()
-        e1.record()
-    finally:
-        _IN_TIMED = False
-    TIMER.append((kernel, flops, nbytes, e0, e1))
-    return r
+def profile_stop(cap=8192):
+    """-> [(kernel name as instantiated, algorithmic flop, algorithmic bytes, milliseconds)] for every launch since profile_start()."""
+    buf = (SmirkProfileRecord * cap)()
+    n = lib().smirk_profile_stop(buf, cap)
+    if n < 0:
+        check(n)
+    return [(buf[i].kernel.decode(), buf[i].flop, buf[i].bytes, buf[i].ms) for i in range(min(n, cap))]
 
 
-class _TimedLib:
-    """Attribute proxy over the CDLL: with TIMER armed, every entry point that enqueues work is timed under its own name (launches that a
-    caller already wrapped in timed() keep the caller's more specific label)."""
-
-    def __init__(self, cdll):
-        object.__setattr__(self, "_cdll", cdll)
-
-    def __getattr__(self, name):
-        fn = getattr(self._cdll, name)
-        if TIMER is None or _IN_TIMED or name.endswith("_bytes") or name in ("smirk_strerror", "smirk_abi_version", "smirk_mbconv_supported"):
-            return fn
-        return lambda *a: timed(name, None, lambda: fn(*a))
+def conv_layer(w, scale=None, shift=None):
+    """SmirkConvLayer from packed device tensors (the caller keeps them alive)."""
+    l = SmirkConvLayer()
+    l.w = w.data_ptr() if w is not None else None
+    l.scale = scale.data_ptr() if scale is not None else None
+    l.shift = shift.data_ptr() if shift is not None else None
+    return l
 
 
-def igemm_kernel_name(n_gemm, split=False, c0=32, c1=0, k=3):
-    """Which conv_igemm_kernel instantiation smirk_conv_igemm_{f32,f16x3} dispatches (mirrors launch_igemm in conv.hip): tile by GEMM N,
-    K-walk mode by channel counts (0 generic, 1 tap-major pointer walk, 2 1x1 with a partial chunk, 4 buffer-addressed tap-major,
-    5 buffer-addressed channel-major).  Used for labelling timings only."""
-    t = "128,128,2,2" if n_gemm > 64 else "128,64,2,2" if n_gemm > 32 else "256,32,4,1"
-    aligned = c0 % 32 == 0 and c1 % 32 == 0
-    kw = 1 if aligned else (2 if k == 1 else 0)
-    if split and aligned and os.environ.get("SMIRK_IGEMM_LEAN", "1") != "0":
-        pow2 = (c0 & (c0 - 1)) == 0 and (c1 & (c1 - 1)) == 0
-        kw = 5 if (k == 3 and pow2 and ((c0 + c1) // 32) % 2 == 0 and n_gemm > 64) else 4
-    return f"conv_igemm_kernel<{t},{'true' if split else 'false'},{kw}>"
+class _LoudCut(torch.autograd.Function):
+    """Identity whose backward raises: attached to the output of a forward that has no backward implementation whenever autograd would
+    otherwise record a (silently broken) graph through it.  Forward-only callers (demo.py runs without torch.no_grad()) are unaffected."""
+
+    @staticmethod
+    def forward(ctx, what, y, *deps):
+        ctx.what = what
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError(f"{ctx.what} has no backward on the HIP path: gradients cannot flow through it "
+                                  "(run it under torch.no_grad(), or detach its inputs)")
+
+
+def loud_cut(what, y, deps):
+    """y if autograd is off or nothing in `deps` requires grad; otherwise y with a grad_fn that raises when back-propagated through."""
+    if not torch.is_grad_enabled():
+        return y
+    deps = [t for t in deps if torch.is_tensor(t) and t.requires_grad]
+    return _LoudCut.apply(what, y, *deps) if deps else y
 
 
 class Workspace:
-    """Grow-only byte scratch buffer owned by a module (the library never allocates)."""
+    """Grow-only byte scratch buffers owned by a module, one per (device, stream): the library never allocates, and two streams that run
+    the same module concurrently (OverlappedPipeline, the encoder's side streams) must not share scratch memory."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
-    def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        return self.buf
+    def get(self, nbytes, device, stream=None):
+        key = (device, torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return buf

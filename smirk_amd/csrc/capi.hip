@@ -12,4 +12,82 @@ extern "C" const char* smirk_strerror(int code) {
     }
 }
 
-extern "C" int smirk_abi_version(void) { return 3; }
+extern "C" int smirk_abi_version(void) { return 4; }
+
+// ---- launch profiler ---------------------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+bool g_smirk_prof_on = false;
+namespace {
+struct ProfRec { char name[120]; double flop, bytes; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_recs;
+std::mutex g_prof_mu;
+thread_local char t_next_name[120];
+thread_local double t_next_flop = 0.0, t_next_bytes = 0.0;
+thread_local bool t_has_name = false;
+thread_local long t_open = -1;
+}  // namespace
+
+void smirk_prof_next(const char* name, double flop, double bytes) {
+    if (!g_smirk_prof_on) return;
+    t_has_name = name != nullptr;
+    if (name) { strncpy(t_next_name, name, sizeof(t_next_name) - 1); t_next_name[sizeof(t_next_name) - 1] = 0; }
+    t_next_flop = flop; t_next_bytes = bytes;
+}
+
+void smirk_prof_begin(const char* name, hipStream_t st) {
+    ProfRec r;
+    const char* src = t_has_name ? t_next_name : name;
+    // "(kernel<1, 2>)" -> "kernel<1,2>"
+    size_t o = 0;
+    for (const char* c = src; *c && o + 1 < sizeof(r.name); ++c) {
+        if (*c == ' ' || ((*c == '(' ) && c == src)) continue;
+        r.name[o++] = *c;
+    }
+    if (o > 0 && r.name[o - 1] == ')' && src[0] == '(') --o;
+    r.name[o] = 0;
+    r.flop = t_next_flop; r.bytes = t_next_bytes;
+    t_has_name = false; t_next_flop = t_next_bytes = 0.0;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { t_open = -1; return; }
+    (void)hipEventRecord(r.e0, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_recs.push_back(r);
+    t_open = (long)g_recs.size() - 1;
+}
+
+void smirk_prof_end(hipStream_t st) {
+    if (t_open < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((size_t)t_open < g_recs.size()) (void)hipEventRecord(g_recs[t_open].e1, st);
+    t_open = -1;
+}
+
+extern "C" int smirk_profile_start(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_recs.clear();
+    g_smirk_prof_on = true;
+    return SMIRK_OK;
+}
+
+extern "C" int smirk_profile_stop(SmirkProfileRecord* out, int cap) {
+    g_smirk_prof_on = false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const int n = (int)g_recs.size();
+    for (int i = 0; i < n; ++i) {
+        ProfRec& r = g_recs[i];
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+        if (out && i < cap) {
+            memset(&out[i], 0, sizeof(out[i]));
+            strncpy(out[i].kernel, r.name, sizeof(out[i].kernel) - 1);
+            out[i].flop = r.flop; out[i].bytes = r.bytes; out[i].ms = ms;
+        }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    g_recs.clear();
+    return n;
+}

@@ -19,3 +19,25 @@ static inline int smirk_launch_status() {
 
 // row of a 32x32 MFMA accumulator register r (0..15) for this lane: (r&3) + 8*(r>>2) + 4*(lane>>5); column = lane&31
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- launch profiler (smirk_profile_start / _stop in capi.hip) -------------------------------------------------------------------
+// Every launch of the library goes through SMIRK_LAUNCH: with the profiler armed the launch is bracketed by two hipEvents on its stream
+// and labelled with the kernel's instantiated name; dispatchers that know the launch's algorithmic work state it just before through
+// smirk_prof_next().  Disarmed (the normal case) the cost is one load and a predictable branch.
+extern bool g_smirk_prof_on;
+void smirk_prof_begin(const char* name, hipStream_t st);
+void smirk_prof_end(hipStream_t st);
+// name (nullable: keep the stringified kernel), algorithmic flop and bytes of the NEXT launch made by this thread
+void smirk_prof_next(const char* name, double flop, double bytes);
+
+struct SmirkLaunchScope {
+    bool on;
+    hipStream_t st;
+    SmirkLaunchScope(const char* name, hipStream_t s) : on(g_smirk_prof_on), st(s) { if (on) smirk_prof_begin(name, s); }
+    ~SmirkLaunchScope() { if (on) smirk_prof_end(st); }
+};
+#define SMIRK_LAUNCH(kernel, grid, block, lds, st, ...)                                   \
+    do {                                                                                  \
+        SmirkLaunchScope smirk_launch_scope_(#kernel, (hipStream_t)(st));                 \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                    \
+    } while (0)

@@ -34,6 +34,7 @@
 //
 // Bound: MFMA (fp32 157.3 TF; f16 2.5 PF issuing 3 MFMA-flop per algorithmic flop) once the operands hit L2; the Infinity Cache's
 // ~7 TB/s otherwise.  Algorithmic flop = 2*M*N*K.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -619,7 +620,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_kernel(ConvArgs 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
 static void launch_igemm_kw(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
+    if (g_smirk_prof_on) {                                       // the profiler's label is the instantiation that is launched HERE
+        char nm[120];
+        snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d,%d,%d,%d,%s,%d>", BM, BN, WGM, WGN, SPLIT ? "true" : "false", KWALK);
+        const double px = (double)a.d.B * a.d.H * a.d.W;
+        smirk_prof_next(nm, 2.0 * a.M * a.N * a.K, 4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
+    }
+    SMIRK_LAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT>
@@ -754,12 +761,12 @@ static unsigned grid_for(size_t total, unsigned cap) { const size_t g = (total +
 
 extern "C" int smirk_f32_to_split16(const float* in, void* out, size_t n_elems, void* stream) {
     if (!in || !out || n_elems % 8) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(f32_to_split16_kernel, dim3(grid_for(n_elems / 8, 16384)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, n_elems / 8);
+    SMIRK_LAUNCH(f32_to_split16_kernel, dim3(grid_for(n_elems / 8, 16384)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, n_elems / 8);
     return smirk_launch_status();
 }
 extern "C" int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, void* stream) {
     if (!in || !out || n_elems % 8) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(split16_to_f32_kernel, dim3(grid_for(n_elems / 8, 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in, out, n_elems / 8);
+    SMIRK_LAUNCH(split16_to_f32_kernel, dim3(grid_for(n_elems / 8, 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in, out, n_elems / 8);
     return smirk_launch_status();
 }
 
@@ -793,7 +800,8 @@ __global__ __launch_bounds__(256) void maxpool2x2_split_kernel(const float* __re
 extern "C" int smirk_maxpool2x2_split16(const void* in, void* out, int B, int H, int W, int C, void* stream) {
     if (!in || !out || B <= 0 || H % 2 || W % 2 || C % 8 || C <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(maxpool2x2_split_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in,
+    smirk_prof_next(nullptr, 0.0, 5.0 * total * 32);          // reads 4 groups, writes 1 (32 bytes per split16 group)
+    SMIRK_LAUNCH(maxpool2x2_split_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in,
                        (float*)out, B, H, W, C / 8);
     return smirk_launch_status();
 }
@@ -822,7 +830,8 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
 extern "C" int smirk_pack_generator_input_split16(const float* a, int Ca, const float* b, int Cb, void* out, int B, int H, int W,
                                                   void* stream) {
     if (!a || !out || B <= 0 || Ca <= 0 || Cb < 0 || Ca + Cb > 8 || (Cb > 0 && !b)) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for((size_t)B * H * W, 16384)), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Cb,
+    smirk_prof_next(nullptr, 0.0, (double)B * H * W * ((Ca + Cb) * 4 + 32));
+    SMIRK_LAUNCH(pack_split_kernel, dim3(grid_for((size_t)B * H * W, 16384)), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Cb,
                        (float*)out, B, H * W);
     return smirk_launch_status();
 }
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_split_kernel(const float*
 extern "C" int smirk_conv1x1_sigmoid_nchw_split16(const void* in, const float* w, const float* bias, float* out, int B, int H,
                                                   int W, int C, int Cout, void* stream) {
     if (!in || !w || !out || B <= 0 || C % 8 || C <= 0 || Cout <= 0 || Cout > 4) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(conv1x1_sigmoid_split_kernel, dim3(grid_for((size_t)B * H * W, 16384)), dim3(256),
+    SMIRK_LAUNCH(conv1x1_sigmoid_split_kernel, dim3(grid_for((size_t)B * H * W, 16384)), dim3(256),
                        (size_t)(Cout * C + Cout) * 4, (hipStream_t)stream, (const float*)in, w, bias, out, B, H * W, C, Cout);
     return smirk_launch_status();
 }
@@ -893,7 +902,7 @@ extern "C" int smirk_maxpool2x2_nhwc(const float* in, float* out, int B, int H, 
     if (!in || !out || B <= 0 || H % 2 || W % 2 || C % 4 || C <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)in, (f32x4*)out, B,
+    SMIRK_LAUNCH(maxpool2x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)in, (f32x4*)out, B,
                        H, W, C / 4);
     return smirk_launch_status();
 }
@@ -924,7 +933,7 @@ extern "C" int smirk_nchw_to_nhwc_pad(const float* in, float* out, int B, int Ci
     if (!in || !out || B <= 0 || Cin <= 0 || Cpad < Cin || Cpad % 4) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * H * W;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, Cin, (const float*)nullptr, 0,
+    SMIRK_LAUNCH(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, Cin, (const float*)nullptr, 0,
                        out, B, H * W, Cpad);
     return smirk_launch_status();
 }
@@ -934,7 +943,7 @@ extern "C" int smirk_pack_generator_input(const float* rendered, const float* ma
     if (!rendered || !masked || !out || B <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * H * W;
     const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rendered, 3, masked, 3, out, B,
+    SMIRK_LAUNCH(nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rendered, 3, masked, 3, out, B,
                        H * W, 8);
     return smirk_launch_status();
 }
@@ -975,7 +984,7 @@ extern "C" int smirk_conv1x1_sigmoid_nchw(const float* in, const float* w, const
     if (!in || !w || !out || B <= 0 || C % 4 || C <= 0 || Cout <= 0 || Cout > 4) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * H * W;
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(conv1x1_sigmoid_kernel, dim3(grid), dim3(256), (size_t)(Cout * C + Cout) * 4, (hipStream_t)stream, in,
+    SMIRK_LAUNCH(conv1x1_sigmoid_kernel, dim3(grid), dim3(256), (size_t)(Cout * C + Cout) * 4, (hipStream_t)stream, in,
                        w, bias, out, B, H * W, C, Cout);
     return smirk_launch_status();
 }

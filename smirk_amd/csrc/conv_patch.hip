@@ -535,11 +535,17 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
         const bool pow2 = (d->C0 & (d->C0 - 1)) == 0 && (d->C1 & (d->C1 - 1)) == 0;
         a.use_buf = (!nb && pow2 && px * d->C0 * 4 < (1ll << 31) && px * d->C1 * 4 < (1ll << 31)) ? 1 : 0;
     }
+    if (g_smirk_prof_on) {
+        const double px = (double)d->B * d->H * d->W, K = 9.0 * (d->C0 + d->C1);
+        const double outb = fout ? px * fcout * 4.0 : px * d->Cout * 4.0;
+        smirk_prof_next(nullptr, 2.0 * px * d->Cout * K + (fout ? 2.0 * px * d->Cout * fcout : 0.0),
+                        px * (d->C0 + d->C1) * 4.0 + outb + K * d->Cout * 4.0);
+    }
     if (!patch_resident(d)) {
         static bool attr2 = false;
         if (!attr2) { (void)hipFuncSetAttribute((const void*)conv3x3_patch_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
         const size_t lds2 = (size_t)(2 * WSTAGE + 2 * PSTAGE) * 4;
-        hipLaunchKernelGGL(conv3x3_patch_stream_kernel, dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), lds2, st, a);
+        SMIRK_LAUNCH(conv3x3_patch_stream_kernel, dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), lds2, st, a);
         return smirk_launch_status();
     }
     const size_t wbytes = (size_t)a.nchunk * 9 * d->Cout * 32 * 4;
@@ -554,9 +560,9 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (d->Cout == 32 && one_stage) hipLaunchKernelGGL((conv3x3_patch_kernel<1, 1>), dim3(grid), dim3(256), lds, st, a);
-    else if (d->Cout == 32) hipLaunchKernelGGL((conv3x3_patch_kernel<1, 2>), dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3_patch_kernel<2, 2>), dim3(grid), dim3(256), lds, st, a);
+    if (d->Cout == 32 && one_stage) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1>), dim3(grid), dim3(256), lds, st, a);
+    else if (d->Cout == 32) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2>), dim3(grid), dim3(256), lds, st, a);
+    else SMIRK_LAUNCH((conv3x3_patch_kernel<2, 2>), dim3(grid), dim3(256), lds, st, a);
     return smirk_launch_status();
 }
 

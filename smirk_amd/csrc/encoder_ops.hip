@@ -75,7 +75,8 @@ static int stem_launch(const float* img, const float* w, const float* scale, con
     if (!img || !w || !scale || !shift || !out || B <= 0 || Cout % 8 || Cout <= 0 || Cout > 64) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), (size_t)29 * Cout * 4, (hipStream_t)stream, img, w, scale,
+    smirk_prof_next(nullptr, 54.0 * B * ((H + 1) / 2) * ((W + 1) / 2) * Cout, 4.0 * ((double)B * 3 * H * W + (double)B * ((H + 1) / 2) * ((W + 1) / 2) * Cout));
+    SMIRK_LAUNCH(stem_conv_kernel, dim3(grid), dim3(256), (size_t)29 * Cout * 4, (hipStream_t)stream, img, w, scale,
                        shift, out, B, H, W, Cout, split);
     return smirk_launch_status();
 }
@@ -178,7 +179,8 @@ extern "C" int smirk_dwconv3x3_split16(const void* in, const float* w, const flo
     if (!in || !w || !scale || !shift || !out || B <= 0 || C % 8 || C <= 0 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * (C / 8);
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(dwconv3x3_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, w, scale, shift,
+    smirk_prof_next(nullptr, 18.0 * total * 8, 4.0 * ((double)B * H * W * C + (double)total * 8));
+    SMIRK_LAUNCH(dwconv3x3_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)in, w, scale, shift,
                        (float*)out, B, H, W, C / 8, stride, relu);
     return smirk_launch_status();
 }
@@ -189,7 +191,7 @@ extern "C" int smirk_dwconv3x3(const float* in, const float* w, const float* sca
         return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * ((H + stride - 1) / stride) * ((W + stride - 1) / stride) * (C / 4);
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)in, (const f32x4*)w,
+    SMIRK_LAUNCH(dwconv3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)in, (const f32x4*)w,
                        (const f32x4*)scale, (const f32x4*)shift, (f32x4*)out, B, H, W, C / 4, stride, relu);
     return smirk_launch_status();
 }
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(256) void gap_linear_kernel(const float* __restrict
 static int gap_launch(const float* feat, const float* w, const float* bias, float* out, float* ws, int B, int HW, int C, int N,
                       void* stream, int split) {
     if (!feat || !w || !out || !ws || B <= 0 || HW <= 0 || C <= 0 || N <= 0 || C > 8192 || (split && C % 8)) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gap_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feat, ws, HW, C, split);
-    hipLaunchKernelGGL(gap_linear_kernel, dim3((N + 63) / 64, B), dim3(256), (size_t)C * 4, (hipStream_t)stream, (const float*)ws, w, bias,
+    SMIRK_LAUNCH(gap_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feat, ws, HW, C, split);
+    SMIRK_LAUNCH(gap_linear_kernel, dim3((N + 63) / 64, B), dim3(256), (size_t)C * 4, (hipStream_t)stream, (const float*)ws, w, bias,
                        out, C, N);
     return smirk_launch_status();
 }
@@ -259,6 +261,6 @@ __global__ void expression_clamps_kernel(float* __restrict__ p, int B, int n_exp
 
 extern "C" int smirk_expression_clamps(float* params, int B, int n_exp, void* stream) {
     if (!params || B <= 0 || n_exp < 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(expression_clamps_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, B, n_exp);
+    SMIRK_LAUNCH(expression_clamps_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, B, n_exp);
     return smirk_launch_status();
 }

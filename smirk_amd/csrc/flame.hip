@@ -584,11 +584,11 @@ extern "C" int smirk_flame_forward(const SmirkFlameModel* m, int B, const float*
     float* amat = (float*)p; p += smirk_align_up((size_t)B * 60 * 4, 256);
     int32_t* lut = (int32_t*)p;
     const FlameDev d = to_dev(m);
-    hipLaunchKernelGGL(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw,
+    SMIRK_LAUNCH(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw,
                        eye, coef, amat, lut);
     dim3 grid(m->VP / FL_BV, (B + FL_BM - 1) / FL_BM);
-    hipLaunchKernelGGL(flame_blend_skin, grid, dim3(256), 0, st, d, B, coef, amat, eyelid, verts, v_posed_out);
-    hipLaunchKernelGGL(flame_landmarks, dim3(B), dim3(256), 0, st, d, B, verts, lut, lmk_fan, lmk_fan3d, lmk_mp);
+    SMIRK_LAUNCH(flame_blend_skin, grid, dim3(256), 0, st, d, B, coef, amat, eyelid, verts, v_posed_out);
+    SMIRK_LAUNCH(flame_landmarks, dim3(B), dim3(256), 0, st, d, B, verts, lut, lmk_fan, lmk_fan3d, lmk_mp);
     if (lut_idx_out) {
         hipError_t e = hipMemcpyAsync(lut_idx_out, lut, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return SMIRK_ERR_LAUNCH;
@@ -600,7 +600,7 @@ extern "C" int smirk_vertices2landmarks(const float* verts, int B, int V, const 
                                         const float* bary, int L, float* out, void* stream) {
     if (!verts || !faces || !faces_idx || !bary || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)B * L;
-    hipLaunchKernelGGL(v2l_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, B, V,
+    SMIRK_LAUNCH(v2l_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, B, V,
                        faces, faces_idx, bary, L, out);
     return smirk_launch_status();
 }
@@ -642,16 +642,16 @@ extern "C" int smirk_flame_backward(const SmirkFlameModel* m, const float* dirs_
     float* dA = (float*)(base + bwd_off(cur, (size_t)B * 60 * 4));
     float* dcoef = (float*)(base + bwd_off(cur, (size_t)B * m->KP * 4));
     // forward quantities (coefficient rows, joint transforms) are recomputed rather than stored
-    hipLaunchKernelGGL(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw, eye, coef, amat, lut);
-    hipLaunchKernelGGL(flame_bwd_gather, dim3(B), dim3(256), 0, st, d, B, g_verts, g_fan, g_fan3d, g_mp, lut_idx, G);
-    hipLaunchKernelGGL(flame_bwd_skin, dim3(B), dim3(256), 0, st, d, B, (const float*)G, v_posed, (const float*)amat, eyelid, gvp, dA,
+    SMIRK_LAUNCH(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw, eye, coef, amat, lut);
+    SMIRK_LAUNCH(flame_bwd_gather, dim3(B), dim3(256), 0, st, d, B, g_verts, g_fan, g_fan3d, g_mp, lut_idx, G);
+    SMIRK_LAUNCH(flame_bwd_skin, dim3(B), dim3(256), 0, st, d, B, (const float*)G, v_posed, (const float*)amat, eyelid, gvp, dA,
                        d_eyelid ? d_eyelid : dcoef /* scratch: dcoef is written by the GEMM afterwards */);
     SmirkConvDesc cd;
     cd.B = B; cd.H = 1; cd.W = 1; cd.C0 = 3 * m->VP; cd.C1 = 0; cd.Cout = m->KP; cd.KH = 1; cd.KW = 1; cd.stride = 1; cd.pad_t = 0; cd.pad_l = 0;
     cd.Ho = 1; cd.Wo = 1; cd.pad_mode = SMIRK_PAD_ZERO; cd.act = SMIRK_ACT_NONE; cd.out_mode = SMIRK_OUT_NHWC;
     const int rc = smirk_conv_igemm_f32(&cd, gvp, nullptr, dirs_t, nullptr, nullptr, nullptr, dcoef, stream);
     if (rc != SMIRK_OK) return rc;
-    hipLaunchKernelGGL(flame_bwd_chain, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw, eye,
+    SMIRK_LAUNCH(flame_bwd_chain, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw, eye,
                        (const float*)dA, (const float*)dcoef, d_shape, d_exp, d_gpose, d_neck, d_jaw, d_eye);
     return smirk_launch_status();
 }

@@ -204,21 +204,21 @@ extern "C" int smirk_scatter_points_mask(const int64_t* points, const int64_t* r
     if (!points || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, (size_t)B * H * W * 4, st) != hipSuccess) return SMIRK_ERR_LAUNCH;
-    hipLaunchKernelGGL(scatter_points_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, st, (const long long*)points, (const long long*)rbound,
+    SMIRK_LAUNCH(scatter_points_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, st, (const long long*)points, (const long long*)rbound,
                        B, L, H, W, out);
     return smirk_launch_status();
 }
 
 extern "C" int smirk_rendered_mask(const float* rendered_img, int B, int C, int H, int W, float* out, void* stream) {
     if (!rendered_img || !out || B <= 0 || C <= 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(rendered_mask_kernel, dim3(nblk((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, rendered_img, B, C, H * W, out);
+    SMIRK_LAUNCH(rendered_mask_kernel, dim3(nblk((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, rendered_img, B, C, H * W, out);
     return smirk_launch_status();
 }
 
 extern "C" int smirk_mask_face_weights(const float* tverts, const float* normals, const int32_t* faces, const float* face_prob,
                                        int B, int V, int F, float* weights, void* stream) {
     if (!tverts || !normals || !faces || !face_prob || !weights || B <= 0 || F <= 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(mask_face_weights_kernel, dim3(nblk((size_t)B * F)), dim3(256), 0, (hipStream_t)stream, tverts, normals, faces,
+    SMIRK_LAUNCH(mask_face_weights_kernel, dim3(nblk((size_t)B * F)), dim3(256), 0, (hipStream_t)stream, tverts, normals, faces,
                        face_prob, B, V, F, weights);
     return smirk_launch_status();
 }
@@ -226,14 +226,14 @@ extern "C" int smirk_mask_face_weights(const float* tverts, const float* normals
 extern "C" int smirk_sample_faces(const float* weights, int B, int F, int num, uint64_t seed, uint64_t offset, int32_t* idx,
                                   float* bary, void* stream) {
     if (!weights || !idx || !bary || B <= 0 || F <= 0 || num <= 0 || F > 38000) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sample_faces_kernel, dim3(B), dim3(1024), (size_t)(F + 32) * 4, (hipStream_t)stream, weights, F, num, seed,
+    SMIRK_LAUNCH(sample_faces_kernel, dim3(B), dim3(1024), (size_t)(F + 32) * 4, (hipStream_t)stream, weights, F, num, seed,
                        offset, idx, bary);
     return smirk_launch_status();
 }
 
 extern "C" int smirk_points_to_pixels(const float* points, int B, int L, int image_size, int64_t* out, void* stream) {
     if (!points || !out || B <= 0 || L <= 0 || image_size <= 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(points_to_pixels_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, (hipStream_t)stream, points, (size_t)B * L,
+    SMIRK_LAUNCH(points_to_pixels_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, (hipStream_t)stream, points, (size_t)B * L,
                        image_size, (long long*)out);
     return smirk_launch_status();
 }
@@ -241,15 +241,15 @@ extern "C" int smirk_points_to_pixels(const float* points, int B, int L, int ima
 extern "C" int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int W, int radius, int complement, void* stream) {
     if (!in || !tmp || !out || B <= 0 || radius < 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)B * H * W;
-    hipLaunchKernelGGL(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in, tmp, B, H, W, radius, 0, complement & 1, 0);
-    hipLaunchKernelGGL(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, out, B, H, W, radius, 1, 0,
+    SMIRK_LAUNCH(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in, tmp, B, H, W, radius, 0, complement & 1, 0);
+    SMIRK_LAUNCH(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, out, B, H, W, radius, 1, 0,
                        (complement >> 1) & 1);
     return smirk_launch_status();
 }
 
 extern "C" int smirk_bernoulli_field(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
     if (!out || n == 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(bernoulli_field_kernel, dim3(nblk((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, p, seed, offset);
+    SMIRK_LAUNCH(bernoulli_field_kernel, dim3(nblk((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, p, seed, offset);
     return smirk_launch_status();
 }
 
@@ -257,7 +257,7 @@ extern "C" int smirk_masking_compose(const float* img, const float* mask, const 
                                      const float* pmask, const float* keep, const float* noise_mult, int B, int C, int H, int W,
                                      int gen_noise, uint64_t seed, uint64_t offset, float* out, void* stream) {
     if (!img || !mask || (!extra_points && !pmask) || !out || B <= 0 || C <= 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(masking_compose_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, img, mask,
+    SMIRK_LAUNCH(masking_compose_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, img, mask,
                        rendered_mask, extra_points, pmask, keep, noise_mult, B, C, H * W, gen_noise, seed, offset, out);
     return smirk_launch_status();
 }
@@ -267,9 +267,29 @@ extern "C" int smirk_transfer_pixels(const float* img, const int64_t* points1, c
     if (!img || !points1 || !points2 || !winner_ws || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(winner_ws, 0xFF, (size_t)B * H * W * 4, st) != hipSuccess) return SMIRK_ERR_LAUNCH;   // -1
-    hipLaunchKernelGGL(transfer_winner_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, st, (const long long*)points2,
+    SMIRK_LAUNCH(transfer_winner_kernel, dim3(nblk((size_t)B * L)), dim3(256), 0, st, (const long long*)points2,
                        (const long long*)rbound, B, L, H, W, winner_ws);
-    hipLaunchKernelGGL(transfer_gather_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, st, img, (const long long*)points1,
+    SMIRK_LAUNCH(transfer_gather_kernel, dim3(nblk((size_t)B * C * H * W)), dim3(256), 0, st, img, (const long long*)points1,
                        (const int*)winner_ws, B, C, L, H, W, out);
+    return smirk_launch_status();
+}
+
+// demo.py:154-156: rsing = randint(0, 2) * 2 - 1, rscale = rand() * (mul - 1) + 1, rbound = (n * (1 / mul) * rscale ** rsing).long() — per image,
+// drawn on the device so the step has no host round trip (the reference draws them on the host and copies them over)
+__global__ __launch_bounds__(256) void point_budget_kernel(long long* __restrict__ rbound, int B, int n_points, float mul, uint64_t seed,
+                                                           uint64_t offset) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t r[4];
+    const uint64_t ctr = offset + (uint64_t)b;
+    philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 3u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float rscale = u01(r[0]) * (mul - 1.0f) + 1.0f;
+    const float f = (r[1] & 1u) ? rscale : 1.0f / rscale;
+    rbound[b] = (long long)((float)n_points * (1.0f / mul) * f);
+}
+
+extern "C" int smirk_random_point_budget(int64_t* rbound, int B, int n_points, float mul, uint64_t seed, uint64_t offset, void* stream) {
+    if (!rbound || B <= 0 || n_points <= 0 || !(mul >= 1.0f)) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(point_budget_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)rbound, B, n_points, mul, seed, offset);
     return smirk_launch_status();
 }

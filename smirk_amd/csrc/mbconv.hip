@@ -306,9 +306,9 @@ extern "C" int smirk_mbconv_supported(int Cin, int mid, int Cout, int stride) {
 template <int S, bool EXP>
 static void mb_launch(const MBArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     const int ks = a.cinp / 16;
-    if (ks == 1) hipLaunchKernelGGL((mbconv_fused_kernel<S, EXP, 1>), grid, dim3(256), lds, st, a);
-    else if (ks == 2) hipLaunchKernelGGL((mbconv_fused_kernel<S, EXP, 2>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((mbconv_fused_kernel<S, EXP, 3>), grid, dim3(256), lds, st, a);
+    if (ks == 1) SMIRK_LAUNCH((mbconv_fused_kernel<S, EXP, 1>), grid, dim3(256), lds, st, a);
+    else if (ks == 2) SMIRK_LAUNCH((mbconv_fused_kernel<S, EXP, 2>), grid, dim3(256), lds, st, a);
+    else SMIRK_LAUNCH((mbconv_fused_kernel<S, EXP, 3>), grid, dim3(256), lds, st, a);
 }
 
 extern "C" int smirk_mbconv_fused_split16(const void* x, const void* wexp, const float* s1, const float* b1, const float* wdw,
@@ -333,6 +333,11 @@ extern "C" int smirk_mbconv_fused_split16(const void* x, const void* wexp, const
     const size_t lds = smirk_mbconv_lds_bytes(Cin, mid, Cout, stride);
     const dim3 grid((unsigned)((size_t)B * a.tiles_x * a.tiles_y));
     hipStream_t st = (hipStream_t)stream;
+    if (g_smirk_prof_on) {
+        const double pin = (double)B * H * W, pout = (double)B * a.Ho * a.Wo;
+        smirk_prof_next(nullptr, 2.0 * (wexp ? pin * Cin * mid : 0.0) + 2.0 * pout * mid * 9 + 2.0 * pout * mid * Cout,
+                        4.0 * (pin * Cin * (residual ? 2 : 1) + pout * Cout));
+    }
     if (stride == 1) { if (wexp) mb_launch<1, true>(a, grid, lds, st); else mb_launch<1, false>(a, grid, lds, st); }
     else { if (wexp) mb_launch<2, true>(a, grid, lds, st); else mb_launch<2, false>(a, grid, lds, st); }
     return smirk_launch_status();

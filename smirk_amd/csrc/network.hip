@@ -1,0 +1,296 @@
+// Whole-network entries of libsmirk_hip.so: ONE host call enqueues every layer of a module's forward on the caller's stream.
+//
+//   smirk_generator_forward   SmirkGenerator.forward   (src/smirk_generator.py:51-86; _block :88-119; ResnetBlock :121-178)
+//   smirk_backbone_forward    one sub-encoder of SmirkEncoder.forward: timm MobileNetV3-minimal features[-1] -> GAP -> Linear (+ clamps)
+//                             (src/smirk_encoder.py:34-45, :66-73, :95-110; backbone per SURVEY.md App. A)
+//
+// These are pure schedules over the per-layer entries of conv.hip / conv_patch.hip / encoder_ops.hip / mbconv.hip: which kernel serves a
+// layer is still decided by those dispatchers.  What moves here is the host-side walk (~60 launches for the generator, ~35-50 per
+// backbone): from Python + ctypes (~15 ms per 128-frame step, more than the GPU time of the step) to straight C++ (a few hundred
+// microseconds), and the activation memory from the framework's allocator to a caller-provided workspace that is laid out once:
+//   * U-Net skip tensors e1..e4 have fixed slots,
+//   * everything else rotates through three scratch slots sized for the largest temporary (a layer reads at most two temporaries —
+//     input and residual — and writes one).
+// No allocation, no synchronisation; every pointer is a device pointer except the weight structs (host structs of device pointers).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct Arena {
+    char* base;
+    size_t off;
+    void* take(size_t bytes) {
+        off = smirk_align_up(off, 256);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+// three rotating scratch slots; pick() returns a slot that holds neither `a` nor `b`
+struct Rot {
+    void* slot[3];
+    void* pick(const void* a, const void* b) const {
+        for (int i = 0; i < 3; ++i)
+            if (slot[i] != a && slot[i] != b) return slot[i];
+        return nullptr;
+    }
+};
+
+inline size_t act_bytes(int B, int H, int W, int C) { return (size_t)B * H * W * C * 4; }
+
+struct GenPlan {
+    void* x;         // packed network input [B][H][W][cin_pad]
+    void* e[4];      // skip tensors
+    Rot rot;
+    size_t total;
+};
+
+GenPlan plan_generator(const SmirkGeneratorWeights* w, int B, int H, int W, void* ws) {
+    Arena a{(char*)ws, 0};
+    GenPlan p;
+    const int f = w->features;
+    p.x = a.take(act_bytes(B, H, W, w->cin_pad));
+    for (int l = 0; l < 4; ++l) p.e[l] = a.take(act_bytes(B, H >> l, W >> l, f << l));
+    const size_t big = act_bytes(B, H, W, f);                       // the largest temporary: enc1conv1 out, up1, dec1conv1 out
+    for (int i = 0; i < 3; ++i) p.rot.slot[i] = a.take(big);
+    p.total = smirk_align_up(a.off, 256);
+    return p;
+}
+
+int conv_call(bool split, const SmirkConvDesc& d, const void* in0, const void* in1, const SmirkConvLayer& L, const void* residual, void* out,
+              void* stream) {
+    return split ? smirk_conv_igemm_f16x3(&d, in0, in1, L.w, L.scale, L.shift, residual, out, stream)
+                 : smirk_conv_igemm_f32(&d, (const float*)in0, (const float*)in1, (const float*)L.w, L.scale, L.shift, (const float*)residual,
+                                        (float*)out, stream);
+}
+
+SmirkConvDesc desc3x3(int B, int H, int W, int c0, int c1, int cout, bool reflect, bool relu) {
+    SmirkConvDesc d;
+    d.B = B; d.H = H; d.W = W; d.C0 = c0; d.C1 = c1; d.Cout = cout; d.KH = d.KW = 3; d.stride = 1; d.pad_t = d.pad_l = 1;
+    d.Ho = H; d.Wo = W; d.pad_mode = reflect ? SMIRK_PAD_REFLECT : SMIRK_PAD_ZERO; d.act = relu ? SMIRK_ACT_RELU : SMIRK_ACT_NONE;
+    d.out_mode = SMIRK_OUT_NHWC;
+    return d;
+}
+
+SmirkConvDesc desc1x1(int B, int H, int W, int cin, int cout, bool relu, bool convt) {
+    SmirkConvDesc d;
+    d.B = B; d.H = H; d.W = W; d.C0 = cin; d.C1 = 0; d.Cout = cout; d.KH = d.KW = 1; d.stride = 1; d.pad_t = d.pad_l = 0;
+    d.Ho = H; d.Wo = W; d.pad_mode = SMIRK_PAD_ZERO; d.act = relu ? SMIRK_ACT_RELU : SMIRK_ACT_NONE;
+    d.out_mode = convt ? SMIRK_OUT_CONVT2X2 : SMIRK_OUT_NHWC;
+    return d;
+}
+
+#define TRY(expr)                      \
+    do {                               \
+        const int rc_ = (expr);        \
+        if (rc_ != SMIRK_OK) return rc_; \
+    } while (0)
+
+bool gen_args_ok(const SmirkGeneratorWeights* w, int B, int H, int W) {
+    if (!w || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return false;
+    if (w->res_blocks < 0 || w->res_blocks > SMIRK_GEN_MAX_RES || w->features <= 0 || w->out_channels <= 0 || w->out_channels > 4) return false;
+    if (w->precision == SMIRK_PRECISION_F16X3) return w->features % 8 == 0 && w->cin_pad == 8 && w->in_channels <= 8;
+    return w->precision == SMIRK_PRECISION_F32 && w->features % 4 == 0 && w->cin_pad % 4 == 0 && w->cin_pad >= w->in_channels;
+}
+
+}  // namespace
+
+extern "C" size_t smirk_generator_workspace_bytes(const SmirkGeneratorWeights* w, int B, int H, int W) {
+    if (!gen_args_ok(w, B, H, W)) return 0;
+    return plan_generator(w, B, H, W, nullptr).total;
+}
+
+extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const float* a, int Ca, const float* b, int Cb, float* y, int B, int H,
+                                       int W, void* const* taps, void* ws, size_t ws_bytes, void* stream) {
+    if (!gen_args_ok(w, B, H, W) || !a || !y || !ws || Ca <= 0 || Cb < 0 || Ca + Cb != w->in_channels || (Cb > 0 && !b)) return SMIRK_ERR_BAD_ARG;
+    if (!w->final_w || !w->final_b) return SMIRK_ERR_BAD_ARG;
+    const GenPlan p = plan_generator(w, B, H, W, ws);
+    if (ws_bytes < p.total) return SMIRK_ERR_WORKSPACE;
+    const bool split = w->precision == SMIRK_PRECISION_F16X3;
+    const int f = w->features;
+
+    // ---- cat + NCHW -> NHWC (+ split) of the network input (smirk_trainer.py:94, demo.py:167) ----------------------------------------
+    if (split) {
+        TRY(smirk_pack_generator_input_split16(a, Ca, b, Cb, p.x, B, H, W, stream));
+    } else if (Cb == 0) {
+        TRY(smirk_nchw_to_nhwc_pad(a, (float*)p.x, B, Ca, H, W, w->cin_pad, stream));
+    } else {
+        if (Ca != 3 || Cb != 3 || w->cin_pad != 8) return SMIRK_ERR_UNSUPPORTED;
+        TRY(smirk_pack_generator_input(a, b, (float*)p.x, B, H, W, stream));
+    }
+    auto pool = [&](const void* in, void* out, int h, int wd, int c) {
+        return split ? smirk_maxpool2x2_split16(in, out, B, h, wd, c, stream) : smirk_maxpool2x2_nhwc((const float*)in, (float*)out, B, h, wd, c, stream);
+    };
+    auto tap = [&](int i, const void* src, size_t bytes) {
+        if (taps && taps[i]) (void)hipMemcpyAsync(taps[i], src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    };
+
+    // ---- encoder1..4 + bottleneck (smirk_generator.py:52-60) ---------------------------------------------------------------------------
+    const void* cur = p.x;
+    int cin = w->cin_pad;
+    const void* bott = nullptr;
+    for (int l = 0; l < 5; ++l) {
+        const int h = H >> l, wd = W >> l, c = f << l;
+        void* t1 = p.rot.pick(cur, nullptr);
+        TRY(conv_call(split, desc3x3(B, h, wd, cin, 0, c, false, true), cur, nullptr, w->enc[l][0], nullptr, t1, stream));
+        void* t2 = l < 4 ? p.e[l] : p.rot.pick(t1, nullptr);
+        TRY(conv_call(split, desc3x3(B, h, wd, c, 0, c, false, true), t1, nullptr, w->enc[l][1], nullptr, t2, stream));
+        tap(l, t2, act_bytes(B, h, wd, c));
+        if (l < 4) {
+            void* pl = p.rot.pick(nullptr, nullptr);
+            TRY(pool(t2, pl, h, wd, c));
+            cur = pl;
+            cin = c;
+        } else {
+            bott = t2;
+        }
+    }
+    // ---- ResNet blocks at H/16 (smirk_generator.py:62-63, :121-178): reflect pad, conv-BN-ReLU, reflect pad, conv-BN, + x -----------------
+    const int h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
+    const void* bcur = bott;
+    for (int k = 0; k < w->res_blocks; ++k) {
+        void* t = p.rot.pick(bcur, nullptr);
+        TRY(conv_call(split, desc3x3(B, h16, w16, c16, 0, c16, true, true), bcur, nullptr, w->res[k][0], nullptr, t, stream));
+        void* o = p.rot.pick(bcur, t);
+        TRY(conv_call(split, desc3x3(B, h16, w16, c16, 0, c16, true, false), t, nullptr, w->res[k][1], bcur, o, stream));
+        bcur = o;
+    }
+    tap(5, bcur, act_bytes(B, h16, w16, c16));
+    // ---- decoder4..1 (smirk_generator.py:65-75): ConvTranspose2d k2 s2, cat with the skip (two-source conv), double conv -------------------
+    const void* dcur = bcur;
+    for (int l = 3; l >= 0; --l) {
+        const int h = H >> l, wd = W >> l, c = f << l;              // output resolution of this level
+        void* up = p.rot.pick(dcur, nullptr);
+        TRY(conv_call(split, desc1x1(B, h / 2, wd / 2, 2 * c, c, false, true), dcur, nullptr, w->up[3 - l], nullptr, up, stream));
+        void* t1 = p.rot.pick(up, nullptr);
+        TRY(conv_call(split, desc3x3(B, h, wd, c, c, c, false, true), up, p.e[l], w->dec[3 - l][0], nullptr, t1, stream));
+        if (l == 0 && split && !taps && f == 32 && H >= 64) {
+            // network tail in one launch: dec1conv2 + BN + ReLU + final 1x1 conv + sigmoid (dec1 never reaches HBM)
+            SmirkConvDesc d = desc3x3(B, h, wd, c, 0, c, false, true);
+            const int rc = smirk_conv3x3_tail_f16x3(&d, t1, nullptr, w->dec[3][1].w, w->dec[3][1].scale, w->dec[3][1].shift, w->final_w, w->final_b,
+                                                    y, w->out_channels, stream);
+            if (rc != SMIRK_ERR_UNSUPPORTED) return rc;
+        }
+        void* t2 = p.rot.pick(t1, nullptr);
+        TRY(conv_call(split, desc3x3(B, h, wd, c, 0, c, false, true), t1, nullptr, w->dec[3 - l][1], nullptr, t2, stream));
+        tap(6 + (3 - l), t2, act_bytes(B, h, wd, c));
+        dcur = t2;
+    }
+    return split ? smirk_conv1x1_sigmoid_nchw_split16(dcur, w->final_w, w->final_b, y, B, H, W, f, w->out_channels, stream)
+                 : smirk_conv1x1_sigmoid_nchw((const float*)dcur, w->final_w, w->final_b, y, B, H, W, f, w->out_channels, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// MobileNetV3-minimal backbone + pooled linear head
+// ------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+bool backbone_args_ok(const SmirkBackboneWeights* w, int B, int H, int W) {
+    if (!w || B <= 0 || H < 32 || W < 32 || w->n_blocks <= 0 || w->n_blocks > SMIRK_BACKBONE_MAX_BLOCKS || w->n_out < 0) return false;
+    if (w->precision != SMIRK_PRECISION_F16X3 && w->precision != SMIRK_PRECISION_F32) return false;
+    if (w->n_out > 0 && (!w->head_w || !w->head_b)) return false;                    // n_out == 0: features only, no head
+    return w->stem.w && w->stem.scale && w->stem.shift && w->stem_cout > 0;
+}
+
+// largest activation (in elements) any layer of the backbone reads or writes, walking the block list
+size_t backbone_max_elems(const SmirkBackboneWeights* w, int B, int H, int W) {
+    int h = (H + 1) / 2, wd = (W + 1) / 2;
+    size_t m = (size_t)B * h * wd * w->stem_cout;
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const SmirkMbBlock& b = w->blocks[i];
+        const int ho = (h + b.stride - 1) / b.stride, wo = (wd + b.stride - 1) / b.stride;
+        const size_t in_mid = (size_t)B * h * wd * b.mid, out_mid = (size_t)B * ho * wo * b.mid, out = (size_t)B * ho * wo * b.cout;
+        if (b.kind == 1 && in_mid > m) m = in_mid;
+        if (b.kind != 2 && out_mid > m) m = out_mid;
+        if (out > m) m = out;
+        h = ho; wd = wo;
+    }
+    return m;
+}
+
+struct BackbonePlan {
+    Rot rot;
+    float* pooled;
+    size_t total;
+};
+
+BackbonePlan plan_backbone(const SmirkBackboneWeights* w, int B, int H, int W, void* ws) {
+    Arena a{(char*)ws, 0};
+    BackbonePlan p;
+    const size_t big = backbone_max_elems(w, B, H, W) * 4;
+    for (int i = 0; i < 3; ++i) p.rot.slot[i] = a.take(big);
+    p.pooled = (float*)a.take((size_t)B * w->feat_ch * 4);
+    p.total = smirk_align_up(a.off, 256);
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t smirk_backbone_workspace_bytes(const SmirkBackboneWeights* w, int B, int H, int W) {
+    if (!backbone_args_ok(w, B, H, W)) return 0;
+    return plan_backbone(w, B, H, W, nullptr).total;
+}
+
+extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float* img, int B, int H, int W, float* out, void* feat_out,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (!backbone_args_ok(w, B, H, W) || !img || !ws || (w->n_out > 0 && !out) || (w->n_out == 0 && !feat_out)) return SMIRK_ERR_BAD_ARG;
+    const BackbonePlan p = plan_backbone(w, B, H, W, ws);
+    if (ws_bytes < p.total) return SMIRK_ERR_WORKSPACE;
+    const bool split = w->precision == SMIRK_PRECISION_F16X3;
+    const bool no_fuse = getenv("SMIRK_DISABLE_MBCONV_FUSED") != nullptr, fuse_ds = getenv("SMIRK_MBCONV_FUSE_DS") != nullptr;   // A/B switches (tests)
+    int h = (H + 1) / 2, wd = (W + 1) / 2;
+    void* x = p.rot.slot[0];
+    TRY(split ? smirk_stem_conv_s2_split16(img, (const float*)w->stem.w, w->stem.scale, w->stem.shift, x, B, H, W, w->stem_cout, stream)
+              : smirk_stem_conv_s2(img, (const float*)w->stem.w, w->stem.scale, w->stem.shift, (float*)x, B, H, W, w->stem_cout, stream));
+    auto pointwise = [&](const void* in, int hh, int ww, int cin, int cout, const SmirkConvLayer& L, bool relu, const void* res, void* o) {
+        return conv_call(split, desc1x1(B, hh, ww, cin, cout, relu, false), in, nullptr, L, res, o, stream);
+    };
+    auto depthwise = [&](const void* in, int hh, int ww, int c, int stride, const SmirkConvLayer& L, void* o) {
+        return split ? smirk_dwconv3x3_split16(in, (const float*)L.w, L.scale, L.shift, o, B, hh, ww, c, stride, 1, stream)
+                     : smirk_dwconv3x3((const float*)in, (const float*)L.w, L.scale, L.shift, (float*)o, B, hh, ww, c, stride, 1, stream);
+    };
+    int c = w->stem_cout;
+    for (int i = 0; i < w->n_blocks; ++i) {
+        const SmirkMbBlock& b = w->blocks[i];
+        if (b.cin != c) return SMIRK_ERR_BAD_ARG;
+        const int ho = (h + b.stride - 1) / b.stride, wo = (wd + b.stride - 1) / b.stride;
+        const void* res = b.skip ? x : nullptr;
+        if (b.kind == 2) {                                          // ConvBnAct 1x1
+            void* o = p.rot.pick(x, nullptr);
+            TRY(pointwise(x, h, wd, b.cin, b.cout, b.pw, true, nullptr, o));
+            x = o;
+        } else if (split && !no_fuse && (b.kind == 1 || fuse_ds) && smirk_mbconv_supported(b.cin, b.mid, b.cout, b.stride)) {
+            void* o = p.rot.pick(x, nullptr);
+            const SmirkConvLayer& proj = b.kind == 1 ? b.pwl : b.pw;
+            TRY(smirk_mbconv_fused_split16(x, b.kind == 1 ? b.pw.w : nullptr, b.kind == 1 ? b.pw.scale : nullptr, b.kind == 1 ? b.pw.shift : nullptr,
+                                           (const float*)b.dw.w, b.dw.scale, b.dw.shift, proj.w, proj.scale, proj.shift, b.skip ? 1 : 0, o, B, h, wd,
+                                           b.cin, b.mid, b.cout, b.stride, stream));
+            x = o;
+        } else if (b.kind == 0) {                                   // DepthwiseSeparable: dw + BN + ReLU -> pw + BN (+ x)
+            void* t = p.rot.pick(x, nullptr);
+            TRY(depthwise(x, h, wd, b.cin, b.stride, b.dw, t));
+            void* o = p.rot.pick(x, t);
+            TRY(pointwise(t, ho, wo, b.cin, b.cout, b.pw, false, res, o));
+            x = o;
+        } else {                                                    // InvertedResidual: pw + BN + ReLU -> dw + BN + ReLU -> pwl + BN (+ x)
+            void* t = p.rot.pick(x, nullptr);
+            TRY(pointwise(x, h, wd, b.cin, b.mid, b.pw, true, nullptr, t));
+            void* u = p.rot.pick(x, t);
+            TRY(depthwise(t, h, wd, b.mid, b.stride, b.dw, u));
+            void* o = p.rot.pick(x, u);
+            TRY(pointwise(u, ho, wo, b.mid, b.cout, b.pwl, false, res, o));
+            x = o;
+        }
+        h = ho; wd = wo; c = b.cout;
+    }
+    if (c != w->feat_ch) return SMIRK_ERR_BAD_ARG;
+    if (feat_out) (void)hipMemcpyAsync(feat_out, x, act_bytes(B, h, wd, c), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (w->n_out == 0) return SMIRK_OK;
+    TRY(split ? smirk_gap_linear_split16(x, w->head_w, w->head_b, out, p.pooled, B, h * wd, c, w->n_out, stream)
+              : smirk_gap_linear((const float*)x, w->head_w, w->head_b, out, p.pooled, B, h * wd, c, w->n_out, stream));
+    if (w->clamp_n_exp >= 0) TRY(smirk_expression_clamps(out, B, w->clamp_n_exp, stream));
+    return SMIRK_OK;
+}

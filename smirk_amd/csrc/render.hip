@@ -257,14 +257,14 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
     short4* fbox = (short4*)p;
     if (normals) nrm = normals;
     const size_t nv = (size_t)B * mesh->V, nk = (size_t)B * mesh->Vf, nf = (size_t)B * mesh->Ff;
-    hipLaunchKernelGGL(render_project, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam, B, mesh->V,
+    SMIRK_LAUNCH(render_project, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam, B, mesh->V,
                        transformed);
-    hipLaunchKernelGGL(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
-    hipLaunchKernelGGL(raster_face_setup, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, transformed,
+    SMIRK_LAUNCH(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
+    SMIRK_LAUNCH(raster_face_setup, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, transformed,
                        frec, fbox);
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     const size_t smem = FACE_CHUNK * 9 * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
-    hipLaunchKernelGGL(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
+    SMIRK_LAUNCH(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
                        (long long*)pix_to_face, bary, zbuf);
     return smirk_launch_status();
 }
@@ -534,13 +534,13 @@ extern "C" int smirk_render_backward(const SmirkRenderMesh* mesh, int B, int H, 
     float* dS = (float*)p; p += ws_normals(mesh, B);
     float* fgrad = (float*)p;
     const size_t nk = (size_t)B * mesh->Vf, nf = (size_t)B * mesh->Ff;
-    hipLaunchKernelGGL(render_bwd_init, dim3(B), dim3(256), 0, st, B, mesh->V, verts, cam, g_transformed, d_verts, d_cam);
+    SMIRK_LAUNCH(render_bwd_init, dim3(B), dim3(256), 0, st, B, mesh->V, verts, cam, g_transformed, d_verts, d_cam);
     if (g_img) {
-        hipLaunchKernelGGL(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
-        hipLaunchKernelGGL(render_bwd_faces, dim3((unsigned)((nf * BWD_LANES + 255) / 256)), dim3(256), 0, st, d, B, H, W, verts, cam,
+        SMIRK_LAUNCH(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
+        SMIRK_LAUNCH(render_bwd_faces, dim3((unsigned)((nf * BWD_LANES + 255) / 256)), dim3(256), 0, st, d, B, H, W, verts, cam,
                            (const float*)nrm, (const long long*)pix_to_face, g_img, fgrad);
-        hipLaunchKernelGGL(render_bwd_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, (const float*)fgrad, dS);
-        hipLaunchKernelGGL(render_bwd_vertices, dim3(B), dim3(256), 0, st, d, B, verts, cam, (const float*)fgrad, (const float*)dS,
+        SMIRK_LAUNCH(render_bwd_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, (const float*)fgrad, dS);
+        SMIRK_LAUNCH(render_bwd_vertices, dim3(B), dim3(256), 0, st, d, B, verts, cam, (const float*)fgrad, (const float*)dS,
                            d_verts, d_cam);
     }
     return smirk_launch_status();
@@ -549,7 +549,7 @@ extern "C" int smirk_render_backward(const SmirkRenderMesh* mesh, int B, int H, 
 extern "C" int smirk_project_landmarks_backward(const float* lmk, const float* cam, const float* g_out, int B, int L, float* d_lmk,
                                                 float* d_cam_accum, void* stream) {
     if (!lmk || !cam || !g_out || !d_lmk || !d_cam_accum || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(project_landmarks_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, lmk, cam, g_out, B, L, d_lmk, d_cam_accum);
+    SMIRK_LAUNCH(project_landmarks_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, lmk, cam, g_out, B, L, d_lmk, d_cam_accum);
     return smirk_launch_status();
 }
 
@@ -584,14 +584,14 @@ extern "C" int smirk_vertex_normals(const SmirkRenderMesh* mesh, int B, const fl
     if (!mesh || !verts || !normals || B <= 0 || mesh->Vf != mesh->V) return SMIRK_ERR_BAD_ARG;   // full mesh only (faces index verts directly)
     const MeshDev d = mesh_dev(mesh);
     const size_t n = (size_t)B * mesh->Vf;
-    hipLaunchKernelGGL(normals_full_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, B, verts, normals);
+    SMIRK_LAUNCH(normals_full_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, B, verts, normals);
     return smirk_launch_status();
 }
 
 extern "C" int smirk_project_landmarks(const float* lmk, const float* cam, int B, int L, float* out, void* stream) {
     if (!lmk || !cam || !out || B <= 0 || L <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)B * L;
-    hipLaunchKernelGGL(project_landmarks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lmk, cam,
+    SMIRK_LAUNCH(project_landmarks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lmk, cam,
                        B, L, out);
     return smirk_launch_status();
 }

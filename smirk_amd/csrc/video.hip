@@ -44,7 +44,7 @@ extern "C" int smirk_warp_affine_u8(const uint8_t* src, int N, int Hs, int Ws, c
                                     float* out_f32_nchw, uint8_t* out_u8_hwc, void* stream) {
     if (!src || !mats || (!out_f32_nchw && !out_u8_hwc) || N <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)N * Ho * Wo;
-    hipLaunchKernelGGL(warp_affine_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, Hs, Ws, mats,
+    SMIRK_LAUNCH(warp_affine_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, Hs, Ws, mats,
                        Ho, Wo, swap_rb, out_f32_nchw, out_u8_hwc);
     return smirk_launch_status();
 }
@@ -91,7 +91,7 @@ extern "C" int smirk_resize_linear_u8(const uint8_t* src, int N, int Hs, int Ws,
                                       uint8_t* out_u8_hwc, void* stream) {
     if (!src || (!out_f32_nchw && !out_u8_hwc) || N <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)N * Ho * Wo;
-    hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, Hs, Ws, Ho,
+    SMIRK_LAUNCH(resize_linear_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, Hs, Ws, Ho,
                        Wo, swap_rb, out_f32_nchw, out_u8_hwc);
     return smirk_launch_status();
 }
@@ -114,7 +114,7 @@ extern "C" int smirk_f32_nchw_to_u8_grid(const float* src, int N, int H, int W, 
                                          void* stream) {
     if (!src || !grid || N <= 0 || H <= 0 || W <= 0 || col0 < 0 || col0 + W > grid_w) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)N * H * W;
-    hipLaunchKernelGGL(f32_to_u8_grid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, H, W, swap_rb,
+    SMIRK_LAUNCH(f32_to_u8_grid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, H, W, swap_rb,
                        grid, grid_w, col0);
     return smirk_launch_status();
 }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restric
 extern "C" int smirk_u8_hwc_to_f32_nchw(const uint8_t* src, int N, int H, int W, int swap_rb, float* dst, void* stream) {
     if (!src || !dst || N <= 0 || H <= 0 || W <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)N * H * W;
-    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, H, W, swap_rb, dst);
+    SMIRK_LAUNCH(u8_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, H, W, swap_rb, dst);
     return smirk_launch_status();
 }
 
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void interp_bilinear_kernel(const float* __res
 extern "C" int smirk_interp_bilinear_f32(const float* src, int NC, int H, int W, int Ho, int Wo, float* dst, void* stream) {
     if (!src || !dst || NC <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)NC * Ho * Wo;
-    hipLaunchKernelGGL(interp_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, NC, H, W, Ho, Wo,
+    SMIRK_LAUNCH(interp_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, NC, H, W, Ho, Wo,
                        dst);
     return smirk_launch_status();
 }
@@ -253,6 +253,6 @@ __global__ __launch_bounds__(256) void hull_mask_kernel(const float* __restrict_
 
 extern "C" int smirk_hull_mask(const float* landmarks, int N, int L, int stride, int H, int W, float* out, void* stream) {
     if (!landmarks || !out || N <= 0 || L <= 0 || L > HULL_MAX_PTS || stride < 2 || H <= 0 || W <= 0) return SMIRK_ERR_BAD_ARG;
-    hipLaunchKernelGGL(hull_mask_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, landmarks, L, stride, H, W, out);
+    SMIRK_LAUNCH(hull_mask_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, landmarks, L, stride, H, W, out);
     return smirk_launch_status();
 }

@@ -194,9 +194,10 @@ def demo_masked_image(img, hull_mask, rendered_img, transformed_vertices, flame_
     rmask = rendered_mask_of(rendered_img)
     npoints, _ = mesh_based_mask_uniform_faces(transformed_vertices, flame_faces, face_probabilities, mask_ratio=mask_ratio * mask_ratio_mul,
                                                IMAGE_SIZE=H)
-    g = torch.Generator().manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
-    rsing = torch.randint(0, 2, (B,), generator=g) * 2 - 1                                    # demo.py:154-156 (host-side scalars per image)
-    rscale = torch.rand((B,), generator=g) * (mask_ratio_mul - 1) + 1
-    rbound = (npoints.size(1) * (1 / mask_ratio_mul) * (rscale ** rsing)).long().to(img.device)
+    # demo.py:154-156 draws rsing / rscale per image on the host and copies the budgets over; here they are drawn on the device (Philox keyed
+    # like the other draws of this module) so the step has no host round trip and can be captured in a hipGraph
+    rbound = torch.empty(B, dtype=torch.int64, device=img.device)
+    seed, off = _rng(B)
+    L.check(L.lib().smirk_random_point_budget(L.ptr(rbound, torch.int64), B, int(npoints.size(1)), float(mask_ratio_mul), seed, off, L.stream_ptr()))
     pmask = points_mask(npoints, H, W, rbound)
     return masking(img, hull_mask, None, mask_dilation_radius, rendered_mask=rmask, _pmask=pmask)

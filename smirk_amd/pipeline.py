@@ -47,8 +47,7 @@ class SmirkPipeline:
                 out['masked_img'] = masked_img
             if masked_img is None:
                 raise ValueError("the generator needs the masked image (or hull_mask=) next to the rendering")
-            x = self.generator.pack_input(rn['rendered_img'], masked_img)      # cat + NCHW->NHWC fused
-            out['reconstructed_img'] = self.generator.forward_nhwc(x)
+            out['reconstructed_img'] = self.generator.forward_pair(rn['rendered_img'], masked_img)     # torch.cat never materialised
         return out
 
 
@@ -87,8 +86,7 @@ class OverlappedPipeline:
                 _, im, hull = masked
                 masked = self.pipe.masked_from_hull(im, hull, out)
                 out['masked_img'] = masked
-            x = g.pack_input(out['rendered_img'], masked)
-            out['reconstructed_img'] = g.forward_nhwc(x)
+            out['reconstructed_img'] = g.forward_pair(out['rendered_img'], masked)
             for t in (out['rendered_img'], masked):
                 t.record_stream(self.gen_stream)
             done = torch.cuda.Event()

@@ -5,8 +5,8 @@ of this package: the architecture is decoded here from the published arch string
 The nn.Module tree only HOLDS parameters under timm's state_dict names (`<enc>.encoder.conv_stem.weight`, `.bn1.*`,
 `.blocks.{stage}.{i}.conv_pw|conv_dw|conv_pwl|conv.weight`, `.bn{1,2,3}.*`, heads `pose_cam_layers.0`, `shape_layers.0`,
 `expression_layers.0`) so the reference's strict checkpoint load (demo.py:56-58) works.  forward() runs on libsmirk_hip.so:
-stem / depthwise / pool+linear as streaming kernels, every pointwise conv on the fp32 MFMA implicit-GEMM kernel with
-BatchNorm(eval) + ReLU + residual fused.  Eval mode only this round.
+each sub-encoder is ONE call of smirk_backbone_forward (csrc/network.hip) that enqueues stem / fused MBConv blocks / depthwise /
+pointwise (MFMA implicit GEMM with BatchNorm(eval) + ReLU + residual fused) / pooled linear head from C.  Eval mode only this round.
 """
 import os
 
@@ -99,6 +99,8 @@ class MobileNetV3Features(nn.Module):
         self.num_features = cin
         self._packed, self._packed_key = None, None
         self._split = False
+        self._wcache = {}
+        self._ws = L.Workspace()
 
     def _key(self):
         return (PRECISION,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
@@ -132,6 +134,72 @@ class MobileNetV3Features(nn.Module):
         self._packed, self._packed_key = P, key
         return P
 
+    def _weights(self, head=None, clamp_n_exp=-1):
+        """SmirkBackboneWeights for smirk_backbone_forward (host struct of device pointers; cached per parameter version and head)."""
+        P = self._pack()
+        hkey = None if head is None else (head.weight.data_ptr(), head.weight._version, head.bias.data_ptr(), head.bias._version)
+        ck = (self._packed_key, hkey, clamp_n_exp)
+        hit = self._wcache.get("w")
+        if hit is not None and hit[0] == ck:
+            return hit[1]
+        w = L.SmirkBackboneWeights()
+        w.precision = L.PRECISION_F16X3 if self._split else L.PRECISION_F32
+        w.clamp_n_exp, w.stem_cout, w.feat_ch = clamp_n_exp, 16, self.num_features
+        w.stem = L.conv_layer(*P["stem"])
+        n = 0
+        for si, st in enumerate(self.blocks):
+            for bi, blk in enumerate(st):
+                if n >= L.BACKBONE_MAX_BLOCKS:
+                    raise L.SmirkHipError("backbone has more blocks than SMIRK_BACKBONE_MAX_BLOCKS")
+                pk, b = P[(si, bi)], w.blocks[n]
+                b.stride = getattr(blk, "stride", 1)
+                b.skip = int(bool(getattr(blk, "skip", False)))
+                if blk.kind == "ds":
+                    b.kind, b.cin, b.mid, b.cout = 0, blk.conv_dw.in_channels, blk.conv_dw.in_channels, blk.conv_pw.out_channels
+                    b.dw, b.pw = L.conv_layer(*pk["dw"]), L.conv_layer(*pk["pw"])
+                elif blk.kind == "ir":
+                    b.kind, b.cin, b.mid, b.cout = 1, blk.conv_pw.in_channels, blk.conv_pw.out_channels, blk.conv_pwl.out_channels
+                    b.pw, b.dw, b.pwl = L.conv_layer(*pk["pw"]), L.conv_layer(*pk["dw"]), L.conv_layer(*pk["pwl"])
+                else:
+                    b.kind, b.cin, b.mid, b.cout = 2, blk.conv.in_channels, blk.conv.in_channels, blk.conv.out_channels
+                    b.pw = L.conv_layer(*pk["pw"])
+                n += 1
+        w.n_blocks = n
+        keep = None
+        if head is not None:
+            hw, hb = head.weight.detach().float().contiguous(), head.bias.detach().float().contiguous()
+            w.n_out, w.head_w, w.head_b = hw.shape[0], hw.data_ptr(), hb.data_ptr()
+            keep = (hw, hb)
+        self._wcache["w"] = (ck, w, keep)
+        return w
+
+    def run(self, img, head=None, clamp_n_exp=-1, want_features=False):
+        """ONE call of smirk_backbone_forward (csrc/network.hip): stem -> blocks -> (global average pool -> Linear `head` (+ clamps)).
+        Returns (head output [B, n_out] or None, last feature map NHWC or None)."""
+        if self.training:
+            raise NotImplementedError("smirk_amd encoders implement the eval-mode forward only (call .eval())")
+        src = img
+        img = L.as_f32c(img.detach())
+        if not img.is_cuda:
+            raise L.SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
+        B, _, H, W = img.shape
+        lib, w = L.lib(), self._weights(head, clamp_n_exp)
+        dev = img.device
+        out = torch.empty(B, w.n_out, device=dev) if head is not None else None
+        feat = torch.empty(B, (H + 31) // 32, (W + 31) // 32, self.num_features, device=dev) if want_features else None
+        nws = lib.smirk_backbone_workspace_bytes(w, B, H, W)
+        if nws == 0:
+            raise L.SmirkHipError("unsupported backbone configuration / image size (H, W >= 32)")
+        ws = self._ws.get(nws, dev)
+        L.check(lib.smirk_backbone_forward(w, L.ptr(img), B, H, W, L.ptr(out, allow_none=True), L.ptr(feat, allow_none=True),
+                                           L.ptr(ws, torch.uint8), nws, L.stream_ptr()))
+        deps = [src] + list(self.parameters()) + ([] if head is None else list(head.parameters()))
+        if out is not None:
+            out = L.loud_cut("smirk_amd encoder forward", out, deps)
+        if feat is not None:
+            feat = L.loud_cut("smirk_amd encoder forward", feat, deps)
+        return out, feat
+
     def _pointwise(self, lib, st, x, pk, relu, residual=None):
         w, sc, sh = pk
         B, H, W, C = x.shape
@@ -144,8 +212,7 @@ class MobileNetV3Features(nn.Module):
         out = torch.empty(B, H, W, w.shape[0], device=x.device)
         P = L.ptr
         fn = lib.smirk_conv_igemm_f16x3 if self._split else lib.smirk_conv_igemm_f32
-        L.timed(L.igemm_kernel_name(w.shape[0], self._split, C, 0, 1), 2.0 * B * H * W * w.shape[0] * C, lambda: L.check(fn(
-            d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st)))
+        L.check(fn(d, P(x), None, P(w), P(sc), P(sh), P(residual, allow_none=True), P(out), st))
         return out
 
     def _depthwise(self, lib, st, x, pk, stride):
@@ -177,9 +244,12 @@ class MobileNetV3Features(nn.Module):
                                                P(out), B, H, W, C, mid, cout, s, st))
         return out
 
-    def forward(self, img):
+    def forward(self, img, _taps=None):
         """img [B,3,H,W] NCHW in [0,1] -> last feature map NHWC [B,H/32,W/32,C] (fp32, or split16 storage when PRECISION == "f16x3":
-        see `features_f32`)."""
+        see `features_f32`).  `_taps` (list) collects the stem output and every block's output (debugging / parity tools)."""
+        if _taps is None and not os.environ.get("SMIRK_PY_LAYER_SCHEDULE"):
+            return self.run(img, want_features=True)[1]
+        # per-layer schedule driven from Python: the debugging twin of smirk_backbone_forward (same kernels, same order), kept for `_taps`
         if self.training:
             raise NotImplementedError("smirk_amd encoders implement the eval-mode forward only (call .eval())")
         lib, st, P = L.lib(), L.stream_ptr(), self._pack()
@@ -189,6 +259,8 @@ class MobileNetV3Features(nn.Module):
         x = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 16, device=img.device)
         L.check((lib.smirk_stem_conv_s2_split16 if self._split else lib.smirk_stem_conv_s2)(L.ptr(img), L.ptr(w), L.ptr(sc), L.ptr(sh), L.ptr(x), B, H, W, 16, st))
         fused = self._split and not os.environ.get("SMIRK_DISABLE_MBCONV_FUSED")
+        if _taps is not None:
+            _taps.append(("stem", x))
         for si, stg in enumerate(self.blocks):
             for bi, blk in enumerate(stg):
                 pk = P[(si, bi)]
@@ -203,6 +275,8 @@ class MobileNetV3Features(nn.Module):
                     x = self._pointwise(lib, st, y, pk["pwl"], relu=False, residual=x if blk.skip else None)
                 else:
                     x = self._pointwise(lib, st, x, pk["pw"], relu=True)
+                if _taps is not None:
+                    _taps.append((f"block{si}.{bi}:{blk.kind}", x))
         return x
 
 
@@ -221,17 +295,6 @@ def create_backbone(backbone_name, pretrained=True):
     return backbone, backbone.feature_info[-1]['num_chs']
 
 
-def _head(lib, feat, lin, split=False):
-    B, h, w, C = feat.shape
-    W_ = lin.weight.detach().float().contiguous()
-    b_ = lin.bias.detach().float().contiguous()
-    out = torch.empty(B, W_.shape[0], device=feat.device)
-    ws = torch.empty(B, C, device=feat.device)
-    fn = lib.smirk_gap_linear_split16 if split else lib.smirk_gap_linear
-    L.check(fn(L.ptr(feat), L.ptr(W_), L.ptr(b_), L.ptr(out), L.ptr(ws), B, h * w, C, W_.shape[0], L.stream_ptr()))
-    return out
-
-
 class PoseEncoder(nn.Module):
     def __init__(self):
         super().__init__()
@@ -247,7 +310,7 @@ class PoseEncoder(nn.Module):
             self.pose_cam_layers[-1].bias[3] = 7
 
     def forward(self, img):
-        pose_cam = _head(L.lib(), self.encoder(img), self.pose_cam_layers[0], self.encoder._split)
+        pose_cam, _ = self.encoder.run(img, self.pose_cam_layers[0])
         return {'pose_params': pose_cam[..., :3], 'cam': pose_cam[..., 3:]}
 
 
@@ -264,7 +327,7 @@ class ShapeEncoder(nn.Module):
             self.shape_layers[-1].bias.mul_(0)
 
     def forward(self, img):
-        return {'shape_params': _head(L.lib(), self.encoder(img), self.shape_layers[0], self.encoder._split)}
+        return {'shape_params': self.encoder.run(img, self.shape_layers[0])[0]}
 
 
 class ExpressionEncoder(nn.Module):
@@ -281,8 +344,7 @@ class ExpressionEncoder(nn.Module):
             self.expression_layers[-1].bias.mul_(0.1)
 
     def forward(self, img):
-        params = _head(L.lib(), self.encoder(img), self.expression_layers[0], self.encoder._split)
-        L.check(L.lib().smirk_expression_clamps(L.ptr(params), params.shape[0], self.n_exp, L.stream_ptr()))
+        params, _ = self.encoder.run(img, self.expression_layers[0], clamp_n_exp=self.n_exp)
         n = self.n_exp
         return {'expression_params': params[..., :n], 'eyelid_params': params[..., n:n + 2],
                 'jaw_params': params[..., n + 2:n + 5]}
@@ -313,7 +375,10 @@ class SmirkEncoder(nn.Module):
         for st, enc in zip(_STREAMS[img.device], (self.pose_encoder, self.shape_encoder, self.expression_encoder)):
             st.wait_event(fork)
             with torch.cuda.stream(st):
-                outputs.update(enc(img))
+                o = enc(img)
+            for t in o.values():                                 # allocated on the side stream, consumed on the caller's
+                t.record_stream(main)
+            outputs.update(o)
             done = torch.cuda.Event()
             done.record(st)
             main.wait_event(done)

@@ -2,9 +2,10 @@
 
 The module tree only HOLDS the parameters, under exactly the reference's state_dict keys (encoder{1-4}.enc{i}conv{1,2}.weight,
 ...norm{1,2}.*, bottleneck.*, resnet_blocks.{k}.conv_block.{1,2,5,6}.*, upconv{1-4}.*, decoder{1-4}.*, conv.* — 178 keys).
-forward() runs on libsmirk_hip.so: NHWC activations, every 3x3 / transposed convolution on the MFMA implicit-GEMM kernel with
-BatchNorm(eval)+ReLU(+residual) fused in the epilogue, reflection padding and the decoder's channel concat done as address
-arithmetic, 2x2 max-pool and the final 1x1+sigmoid as vectorised streaming kernels.
+forward() is ONE call of smirk_generator_forward (csrc/network.hip), which enqueues the whole layer schedule from C: NHWC activations in a
+per-stream workspace, every 3x3 / transposed convolution on the MFMA implicit-GEMM or halo-patch kernels with BatchNorm(eval)+ReLU(+residual)
+fused in the epilogue, reflection padding and the decoder's channel concat done as address arithmetic, 2x2 max-pool as a vectorised streaming
+kernel, and the network tail (dec1conv2 + BN + ReLU + 1x1 conv + sigmoid) fused into one launch.
 
 Two arithmetic modes (`SmirkGenerator.precision`, default from $SMIRK_AMD_GENERATOR_PRECISION or "f16x3"):
   "f16x3"  split-fp16: activations/weights carried as fp16 (hi, lo) pairs, 3 fp16 MFMAs per product with fp32 accumulation —
@@ -89,6 +90,8 @@ class SmirkGenerator(nn.Module):
         if f % 4 or out_channels > 4:
             raise L.SmirkHipError("gfx950 generator kernels need init_features % 4 == 0 and out_channels <= 4")
         self._packed, self._packed_key = None, None
+        self._wstruct, self._wstruct_key = None, None
+        self._ws = L.Workspace()
         self.precision = os.environ.get("SMIRK_AMD_GENERATOR_PRECISION", "f16x3")
 
     # ---- weight packing (device-side, cached until a parameter changes) ---------------------------------------------------
@@ -133,107 +136,66 @@ class SmirkGenerator(nn.Module):
         self._packed, self._packed_key = P, key
         return P
 
-    # ---- kernel calls ---------------------------------------------------------------------------------------------
-    def _conv(self, lib, st, x0, x1, pk, B, H, W, cout, k=3, reflect=False, relu=True, residual=None, convt=False):
-        w, scale, shift = pk
-        d = L.SmirkConvDesc()
-        d.B, d.H, d.W = B, H, W
-        d.C0, d.C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
-        d.Cout, d.KH, d.KW, d.stride = cout, k, k, 1
-        d.pad_t = d.pad_l = (k - 1) // 2
-        d.Ho, d.Wo = H, W
-        d.pad_mode = L.PAD_REFLECT if reflect else L.PAD_ZERO
-        d.act = L.ACT_RELU if relu else L.ACT_NONE
-        d.out_mode = L.OUT_CONVT2X2 if convt else L.OUT_NHWC
-        out = torch.empty((B, 2 * H, 2 * W, cout) if convt else (B, H, W, cout), device=x0.device)
-        P = L.ptr
-        n_gemm = 4 * cout if convt else cout
-        flops = 2.0 * B * H * W * n_gemm * (k * k * (d.C0 + d.C1))
-        fn = lib.smirk_conv_igemm_f16x3 if self._split else lib.smirk_conv_igemm_f32
-        L.timed(L.igemm_kernel_name(n_gemm, self._split, d.C0, d.C1, k), flops, lambda: L.check(fn(
-            d, P(x0), P(x1, allow_none=True), P(w), P(scale, allow_none=True), P(shift, allow_none=True),
-            P(residual, allow_none=True), P(out), st)))
-        return out
+    def _weights(self):
+        """SmirkGeneratorWeights (host struct of device pointers into the packed tensors) for smirk_generator_forward; rebuilt with the pack."""
+        P = self._pack()
+        if self._wstruct is not None and self._wstruct_key == self._packed_key:
+            return self._wstruct
+        if len(self.resnet_blocks) > L.GEN_MAX_RES:
+            raise L.SmirkHipError(f"at most {L.GEN_MAX_RES} ResNet blocks")
+        w = L.SmirkGeneratorWeights()
+        w.in_channels, w.out_channels, w.features, w.res_blocks = self.in_channels, self.out_channels, self.features, len(self.resnet_blocks)
+        w.precision = L.PRECISION_F16X3 if self._split else L.PRECISION_F32
+        w.cin_pad = self._cin_pad
+        for l, tag in enumerate(("enc1", "enc2", "enc3", "enc4", "bottleneck")):
+            w.enc[l][0], w.enc[l][1] = L.conv_layer(*P[tag + "1"]), L.conv_layer(*P[tag + "2"])
+        for k in range(len(self.resnet_blocks)):
+            w.res[k][0], w.res[k][1] = L.conv_layer(*P[f"res{k}a"]), L.conv_layer(*P[f"res{k}b"])
+        for i, lvl in enumerate((4, 3, 2, 1)):
+            w.up[i] = L.conv_layer(*P[f"up{lvl}"])
+            w.dec[i][0], w.dec[i][1] = L.conv_layer(*P[f"dec{lvl}1"]), L.conv_layer(*P[f"dec{lvl}2"])
+        w.final_w, w.final_b = P["final"][0].data_ptr(), P["final"][2].data_ptr()
+        self._wstruct, self._wstruct_key = w, self._packed_key
+        return w
 
-    def forward_nhwc(self, x_nhwc, taps=None):
-        """x_nhwc [B,H,W,Cpad] (fp32 NHWC in "f32" mode, split16 in "f16x3" mode; channels >= in_channels zero)
-        -> [B,out_channels,H,W] fp32 sigmoid image.  `taps` collects intermediate activations in the mode's storage format."""
+    TAPS = ("enc1", "enc2", "enc3", "enc4", "bottleneck", "res", "dec4", "dec3", "dec2", "dec1")
+
+    def _run(self, a, b, taps=None):
+        """One call of smirk_generator_forward: cat(a, b) NCHW -> sigmoid image.  Every layer is enqueued from C on the current stream; the
+        activations live in a per-stream workspace owned by this module."""
         if self.training:
             raise NotImplementedError("smirk_amd.SmirkGenerator implements the eval-mode forward only (call .eval())")
-        lib, st, P = L.lib(), L.stream_ptr(), self._pack()
-        B, H, W, _ = x_nhwc.shape
+        srcs = [a] + ([] if b is None else [b])
+        a = L.as_f32c(a.detach())
+        b = None if b is None else L.as_f32c(b.detach())
+        B, Ca, H, W = a.shape
+        Cb = 0 if b is None else b.shape[1]
+        if Ca + Cb != self.in_channels:
+            raise L.SmirkHipError(f"expected {self.in_channels} input channels, got {Ca + Cb}")
         if H % 16 or W % 16:
             raise L.SmirkHipError("input size must be a multiple of 16 (4 pooling levels)")
-        f = self.features
-        t = taps if taps is not None else {}
+        lib, w = L.lib(), self._weights()
+        dev = a.device
+        out = torch.empty(B, self.out_channels, H, W, device=dev)
+        tp = None
+        if taps is not None:
+            f = self.features
+            shapes = [(H >> l, W >> l, f << l) for l in range(5)] + [(H >> 4, W >> 4, f << 4)] + [(H >> l, W >> l, f << l) for l in (3, 2, 1, 0)]
+            bufs = [torch.empty(B, h, wd, c, device=dev) for h, wd, c in shapes]
+            tp = (L._p * 10)(*[t.data_ptr() for t in bufs])
+            taps.update(dict(zip(self.TAPS, bufs)))
+        nws = lib.smirk_generator_workspace_bytes(w, B, H, W)
+        ws = self._ws.get(nws, dev)
+        L.check(lib.smirk_generator_forward(w, L.ptr(a), Ca, L.ptr(b, allow_none=True), Cb, L.ptr(out), B, H, W, tp, L.ptr(ws, torch.uint8), nws,
+                                            L.stream_ptr()))
+        # the reference back-propagates through the generator (smirk_trainer.py:94-104); this forward has no backward yet, so make any
+        # attempt to do so fail loudly instead of handing the caller zero / missing gradients
+        return L.loud_cut("smirk_amd.SmirkGenerator.forward", out, srcs + list(self.parameters()))
 
-        def dconv(x0, x1, tag, h, w, c):
-            y = self._conv(lib, st, x0, x1, P[tag + "1"], B, h, w, c)
-            return self._conv(lib, st, y, None, P[tag + "2"], B, h, w, c)
-
-        def pool(x, h, w, c):
-            o = torch.empty(B, h // 2, w // 2, c, device=x.device)
-            L.check((lib.smirk_maxpool2x2_split16 if self._split else lib.smirk_maxpool2x2_nhwc)(L.ptr(x), L.ptr(o), B, h, w, c, st))
-            return o
-
-        e1 = dconv(x_nhwc, None, "enc1", H, W, f); t["enc1"] = e1
-        e2 = dconv(pool(e1, H, W, f), None, "enc2", H // 2, W // 2, 2 * f); t["enc2"] = e2
-        e3 = dconv(pool(e2, H // 2, W // 2, 2 * f), None, "enc3", H // 4, W // 4, 4 * f); t["enc3"] = e3
-        e4 = dconv(pool(e3, H // 4, W // 4, 4 * f), None, "enc4", H // 8, W // 8, 8 * f); t["enc4"] = e4
-        h16, w16 = H // 16, W // 16
-        b = dconv(pool(e4, H // 8, W // 8, 8 * f), None, "bottleneck", h16, w16, 16 * f); t["bottleneck"] = b
-        for k in range(len(self.resnet_blocks)):
-            y = self._conv(lib, st, b, None, P[f"res{k}a"], B, h16, w16, 16 * f, reflect=True, relu=True)
-            b = self._conv(lib, st, y, None, P[f"res{k}b"], B, h16, w16, 16 * f, reflect=True, relu=False, residual=b)
-        t["res"] = b
-        d = b
-        out = torch.empty(B, self.out_channels, H, W, device=b.device)
-        wf, _, bf = P["final"]
-        for lvl, skip, div, c in ((4, e4, 16, 8 * f), (3, e3, 8, 4 * f), (2, e2, 4, 2 * f), (1, e1, 2, f)):
-            up = self._conv(lib, st, d, None, P[f"up{lvl}"], B, H // div, W // div, c, k=1, relu=False, convt=True)
-            if lvl == 1 and self._split and taps is None and f == 32 and H % 16 == 0 and W % 16 == 0 and H >= 64:
-                # network tail fused: dec1conv2 + BN + ReLU + final 1x1 conv + sigmoid in one launch, dec1 never written to HBM
-                y = self._conv(lib, st, up, skip, P["dec11"], B, H, W, f)
-                w2, sc2, sh2 = P["dec12"]
-                dd = L.SmirkConvDesc()
-                dd.B, dd.H, dd.W, dd.C0, dd.C1, dd.Cout, dd.KH, dd.KW, dd.stride = B, H, W, f, 0, f, 3, 3, 1
-                dd.pad_t = dd.pad_l = 1
-                dd.Ho, dd.Wo, dd.pad_mode, dd.act, dd.out_mode = H, W, L.PAD_ZERO, L.ACT_RELU, L.OUT_NHWC
-                Pp = L.ptr
-                flops = 2.0 * B * H * W * f * 9 * f
-                L.timed("conv3x3_patch_kernel", flops, lambda: L.check(lib.smirk_conv3x3_tail_f16x3(
-                    dd, Pp(y), None, Pp(w2), Pp(sc2), Pp(sh2), Pp(wf), Pp(bf), Pp(out), self.out_channels, st)))
-                return out
-            d = dconv(up, skip, f"dec{lvl}", 2 * H // div, 2 * W // div, c)
-            t[f"dec{lvl}"] = d
-        fin = lib.smirk_conv1x1_sigmoid_nchw_split16 if self._split else lib.smirk_conv1x1_sigmoid_nchw
-        L.check(fin(L.ptr(d), L.ptr(wf), L.ptr(bf), L.ptr(out), B, H, W, f, self.out_channels, st))
-        return out
-
-    def pack_input(self, rendered, masked):
-        """Fused torch.cat([rendered, masked], 1) + NCHW->NHWC (smirk_trainer.py:94, demo.py:167) for 3+3 channel inputs."""
-        rendered, masked = L.as_f32c(rendered), L.as_f32c(masked)
-        B, _, H, W = rendered.shape
-        self._pack()
-        if self._cin_pad != 8 or rendered.shape[1] != 3 or masked.shape[1] != 3:
-            raise L.SmirkHipError("pack_input is the 3+3 channel case (SmirkGenerator(in_channels=6, ...))")
-        x = torch.empty(B, H, W, 8, device=rendered.device)
-        if self._split:
-            L.check(L.lib().smirk_pack_generator_input_split16(L.ptr(rendered), 3, L.ptr(masked), 3, L.ptr(x), B, H, W, L.stream_ptr()))
-        else:
-            L.check(L.lib().smirk_pack_generator_input(L.ptr(rendered), L.ptr(masked), L.ptr(x), B, H, W, L.stream_ptr()))
-        return x
+    def forward_pair(self, rendered, masked, _taps=None):
+        """generator(torch.cat([rendered, masked], 1)) without materialising the concatenation (smirk_trainer.py:94, demo.py:167)."""
+        return self._run(rendered, masked, _taps)
 
     def forward(self, x, _taps=None):
         """x [B,in_channels,H,W] (NCHW, like the reference: cat[rendered_img, masked_img]) -> sigmoid image [B,out,H,W]."""
-        x = L.as_f32c(x)
-        B, C, H, W = x.shape
-        if C != self.in_channels:
-            raise L.SmirkHipError(f"expected {self.in_channels} input channels, got {C}")
-        self._pack()
-        xn = torch.empty(B, H, W, self._cin_pad, device=x.device)
-        if self._split:
-            L.check(L.lib().smirk_pack_generator_input_split16(L.ptr(x), C, None, 0, L.ptr(xn), B, H, W, L.stream_ptr()))
-        else:
-            L.check(L.lib().smirk_nchw_to_nhwc_pad(L.ptr(x), L.ptr(xn), B, C, H, W, self._cin_pad, L.stream_ptr()))
-        return self.forward_nhwc(xn, _taps)
+        return self._run(x, None, _taps)

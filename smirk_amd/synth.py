@@ -142,21 +142,53 @@ def synth_generator_input(B, seed=0):
 
 
 def he_init_(module, seed=0):
-    """Seeded He-normal initialisation (std = sqrt(2 / fan_in)) of every conv / transposed-conv weight of a parameter-holder module, BatchNorm
-    left at identity: random-init weights of the reference architecture whose activations stay O(1) through all layers (benchmarks; the
-    default nn.Conv2d init shrinks activations ~2.4x per layer, which after 30 layers is numerically meaningless)."""
+    """Seeded He-normal initialisation of every conv / transposed-conv weight of a parameter-holder module (std = sqrt(2 / fan_in) in front
+    of a ReLU, sqrt(1 / fan_in) for the linear projections: MobileNetV3 `conv_pwl`, the DepthwiseSeparable block's `conv_pw`, the second
+    conv of a ResnetBlock, ConvTranspose2d), BatchNorm left at identity: random-init weights of the reference architecture whose activations
+    stay O(1) through all layers (benchmarks; nn.Conv2d's default init shrinks activations ~2.4x per layer, which after 30 layers is
+    numerically meaningless)."""
     import torch
     import torch.nn as nn
     g = torch.Generator().manual_seed(seed)
+    mods = dict(module.named_modules())
     with torch.no_grad():
-        for m in module.modules():
+        for name, m in mods.items():
             if isinstance(m, nn.ConvTranspose2d):          # weight [Cin, Cout, kh, kw]; stride == kernel => each output sees Cin inputs
                 m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (1.0 / m.weight.shape[0]) ** 0.5)
                 if m.bias is not None:
                     m.bias.zero_()
             elif isinstance(m, nn.Conv2d):
+                parent = mods.get(name.rsplit(".", 1)[0]) if "." in name else None
+                linear = name.endswith("conv_pwl") or name.endswith("conv_block.5") or \
+                    (name.endswith("conv_pw") and getattr(parent, "kind", None) == "ds")
                 fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
-                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * ((1.0 if linear else 2.0) / fan_in) ** 0.5)
                 if m.bias is not None:
                     m.bias.zero_()
     return module
+
+
+def calibrate_encoder_heads_(enc, device, seed=4242, n_exp=50):
+    """Rescale the three linear heads of a random-init SmirkEncoder (already on `device`) so that the regressed FLAME / camera parameters fall
+    in the ranges the trained network produces (pose +-0.4, cam scale ~8, |t| < 0.1, shape ~N(0, 0.5), exp ~N(0, 1), jaw[0] in [0, .5], eyelids in
+    [0, 1]) — otherwise a random backbone's O(100) features drive FLAME into pathological meshes that no real frame produces (and that cost the
+    rasteriser 50x its normal time).  Uses the product's own backbone forward on 16 synthetic frames; benchmark set-up only."""
+    import torch
+    from .smirk_encoder import features_f32
+    g = torch.Generator().manual_seed(seed)
+    x = synth_images(16, seed=seed).to(device)
+    plan = ((enc.pose_encoder.encoder, enc.pose_encoder.pose_cam_layers[0], [0, 0, 0, 8, 0, 0], [.15, .15, .15, .7, .03, .03]),
+            (enc.shape_encoder.encoder, enc.shape_encoder.shape_layers[0], [0.0], [0.5]),
+            (enc.expression_encoder.encoder, enc.expression_encoder.expression_layers[0], [0.0] * n_exp + [.5, .5, .2, 0, 0],
+             [1.0] * n_exp + [.3, .3, .15, .1, .1]))
+    with torch.no_grad():
+        for bb, lin, mean, std in plan:
+            f = features_f32(bb, bb(x)).float().mean((1, 2)).cpu()                # [16, C] pooled features
+            mu, sg = f.mean(0), f.std(0).clamp_min(1e-3 * f.abs().mean().clamp_min(1e-12))
+            C, n = f.shape[1], lin.out_features
+            mean = torch.tensor(mean, dtype=torch.float32).expand(n) if len(mean) == 1 else torch.tensor(mean, dtype=torch.float32)
+            std = torch.tensor(std, dtype=torch.float32).expand(n) if len(std) == 1 else torch.tensor(std, dtype=torch.float32)
+            W = torch.randn(n, C, generator=g) / C ** 0.5 / sg[None] * std[:, None]
+            lin.weight.copy_(W.to(lin.weight.device))
+            lin.bias.copy_((mean - W @ mu).to(lin.bias.device))
+    return enc

@@ -52,11 +52,11 @@ def test_generator_layerwise_vs_oracle(gen):
     assert (yg.cpu() - yr).abs().max().item() < OUT_TOL
 
 
-def test_generator_pack_input_equals_cat(gen):
+def test_generator_forward_pair_equals_cat(gen):
     m, _ = gen
     x = A.synth_generator_input(2, seed=8).cuda()
     y0 = m(x)
-    y1 = m.forward_nhwc(m.pack_input(x[:, :3].contiguous(), x[:, 3:].contiguous()))
+    y1 = m.forward_pair(x[:, :3].contiguous(), x[:, 3:].contiguous())            # two-source entry: the cat is never materialised
     assert torch.equal(y0, y1)
 
 

@@ -44,7 +44,7 @@ def t_stream(fn, stream, n=5):
 def front(): 
     e = enc(img); f = flame.forward(e); return rend.forward(f["vertices"], e["cam"])
 def generate():
-    return gen.forward_nhwc(gen.pack_input(rendered, masked))
+    return gen.forward_pair(rendered, masked)
 
 full = torch.cuda.Stream()
 print(f"unmasked: front {t_stream(front, full):.2f} ms, generator {t_stream(generate, full):.2f} ms")
