@@ -241,6 +241,8 @@ class Workspace:
         self.bufs = {}
 
     def get(self, nbytes, device, stream=None):
+        if torch.device(device).type != "cuda":
+            raise SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor / module (no CPU fallback exists)")
         key = (device, torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:

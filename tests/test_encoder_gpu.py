@@ -27,7 +27,8 @@ def enc():
 def test_encoder_matches_reference_golden(enc, golden_dir):
     m, sd = enc
     g = np.load(os.path.join(golden_dir, "encoder_golden.npz"))
-    out = m(A.synth_images(2, seed=int(g["seed"])).cuda())
+    with torch.no_grad():
+        out = m(A.synth_images(2, seed=int(g["seed"])).cuda())
     for k, tol in TOL.items():
         assert np.abs(out[k].cpu().numpy() - g[k]).max() < tol, k
 
