@@ -1,0 +1,66 @@
+"""Unwritten-output / uninitialised-read detector: every buffer the modules obtain from torch.empty (outputs AND workspaces) is pre-filled with
+0xFF bytes (NaN as fp32, -1 as int).  The pipeline's results must equal the results of an ordinary run bit for bit; any element a kernel fails to
+write, or any scratch value it reads before writing, shows up as NaN / a difference.       python tools/poison_check.py [B]   (GPU box)"""
+import os
+import sys
+import tempfile
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import assets as A                      # noqa: E402
+from oracle import generator_ref as G               # noqa: E402
+from oracle import mobilenet_ref as M               # noqa: E402
+
+_real_empty = torch.empty
+FILL = [0xFF]
+
+
+def poisoned_empty(*size, **kw):
+    t = _real_empty(*size, **kw)
+    if t.is_cuda and t.numel():
+        t.view(torch.uint8).fill_(FILL[0]) if t.is_contiguous() else None
+    return t
+
+
+def main():
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, masking as MK, synth
+    from smirk_amd.pipeline import SmirkPipeline
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    sb = tempfile.mkdtemp()
+    synth.write_sandbox(sb)
+    cwd = os.getcwd(); os.chdir(sb)
+    try:
+        fl, rn = FLAME().cuda(), Renderer().cuda()
+    finally:
+        os.chdir(cwd)
+    enc = SmirkEncoder(); enc.load_state_dict(M.synth_encoder_state_dict()); enc = enc.cuda().eval()
+    gen = SmirkGenerator(6, 3, 32, 5); gen.load_state_dict(G.synth_state_dict()); gen = gen.cuda().eval()
+    img = A.synth_images(B, seed=7002).cuda()
+    masked = A.synth_generator_input(B, seed=7002)[:, 3:].contiguous().cuda()
+    pipe = SmirkPipeline(enc, fl, rn, gen)
+    ref = pipe(img, masked)
+    torch.cuda.synchronize()
+    torch.empty = poisoned_empty
+    try:
+        for fill in (0xFF, 0x7F, 0x00):
+            FILL[0] = fill
+            # fresh workspaces too: drop the modules' cached scratch buffers so that they are re-created (poisoned) by this pass
+            for m in (fl, rn, gen, enc.pose_encoder.encoder, enc.shape_encoder.encoder, enc.expression_encoder.encoder):
+                m._ws.bufs.clear()
+            got = pipe(img, masked)
+            torch.cuda.synchronize()
+            bad = []
+            for k, v in ref.items():
+                if torch.is_tensor(v) and not torch.equal(v, got[k]):
+                    d = (v.float() - got[k].float())
+                    nan = int(torch.isnan(got[k].float()).sum())
+                    bad.append(f"{k}: n_diff={int((v != got[k]).sum())} nan={nan} max={d.abs().nan_to_num(0).max().item():.3e}")
+            print(f"fill=0x{fill:02X}: {'identical' if not bad else ' | '.join(bad)}", flush=True)
+    finally:
+        torch.empty = _real_empty
+
+
+if __name__ == "__main__":
+    main()
