@@ -14,6 +14,8 @@
 // ((10/8)^2 = 1.56x at stride 1, 1.13x at stride 2) + the output — 5-8x less than the unfused sequence at 112^2..28^2.
 // Bound: HBM at 112^2/56^2 (then latency: 2 barriers per 32-channel chunk); arithmetic identical in kind to the unfused kernels
 // (f16x3 products, fp32 accumulation, fp32 depthwise), E is kept in fp32 instead of being rounded to split16 in between.
+#include <stdio.h>
+
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -304,8 +306,13 @@ extern "C" int smirk_mbconv_supported(int Cin, int mid, int Cout, int stride) {
 }
 
 template <int S, bool EXP>
-static void mb_launch(const MBArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+static void mb_launch(const MBArgs& a, dim3 grid, size_t lds, hipStream_t st, double flop, double bytes) {
     const int ks = a.cinp / 16;
+    if (g_smirk_prof_on) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "mbconv_fused_kernel<%d,%s,%d>", S, EXP ? "true" : "false", ks);
+        smirk_prof_next(nm, flop, bytes);
+    }
     if (ks == 1) SMIRK_LAUNCH((mbconv_fused_kernel<S, EXP, 1>), grid, dim3(256), lds, st, a);
     else if (ks == 2) SMIRK_LAUNCH((mbconv_fused_kernel<S, EXP, 2>), grid, dim3(256), lds, st, a);
     else SMIRK_LAUNCH((mbconv_fused_kernel<S, EXP, 3>), grid, dim3(256), lds, st, a);
@@ -333,12 +340,10 @@ extern "C" int smirk_mbconv_fused_split16(const void* x, const void* wexp, const
     const size_t lds = smirk_mbconv_lds_bytes(Cin, mid, Cout, stride);
     const dim3 grid((unsigned)((size_t)B * a.tiles_x * a.tiles_y));
     hipStream_t st = (hipStream_t)stream;
-    if (g_smirk_prof_on) {
-        const double pin = (double)B * H * W, pout = (double)B * a.Ho * a.Wo;
-        smirk_prof_next(nullptr, 2.0 * (wexp ? pin * Cin * mid : 0.0) + 2.0 * pout * mid * 9 + 2.0 * pout * mid * Cout,
-                        4.0 * (pin * Cin * (residual ? 2 : 1) + pout * Cout));
-    }
-    if (stride == 1) { if (wexp) mb_launch<1, true>(a, grid, lds, st); else mb_launch<1, false>(a, grid, lds, st); }
-    else { if (wexp) mb_launch<2, true>(a, grid, lds, st); else mb_launch<2, false>(a, grid, lds, st); }
+    const double pin = (double)B * H * W, pout = (double)B * a.Ho * a.Wo;
+    const double flop = 2.0 * (wexp ? pin * Cin * mid : 0.0) + 2.0 * pout * mid * 9 + 2.0 * pout * mid * Cout;
+    const double bytes = 4.0 * (pin * Cin * (residual ? 2 : 1) + pout * Cout);
+    if (stride == 1) { if (wexp) mb_launch<1, true>(a, grid, lds, st, flop, bytes); else mb_launch<1, false>(a, grid, lds, st, flop, bytes); }
+    else { if (wexp) mb_launch<2, true>(a, grid, lds, st, flop, bytes); else mb_launch<2, false>(a, grid, lds, st, flop, bytes); }
     return smirk_launch_status();
 }
