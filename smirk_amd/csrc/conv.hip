@@ -40,46 +40,7 @@
 #include "common.h"
 #include <type_traits>
 
-#define CV_BK 32
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-struct ConvArgs {
-    SmirkConvDesc d;
-    const float *in0, *in1, *w, *scale, *shift, *residual;   // F16X3: in0/in1/w/residual/out are split-fp16 tensors viewed as dwords
-    float* out;
-    int M, N, K, Cin;
-    int ablate;    // reserved for ablation experiments (unused in the shipped kernels)
-    int psh;       // GEMM rows enumerate each image in (2^psh x 2^psh)-pixel patches (tile-major): a BM-row tile is then a compact 2-D
-                   // patch whose 3x3 halo is ~1.3x its area instead of 3 full image rows — the im2col re-reads stay in L1/L2
-};
-
-// GEMM row -> (image, y, x).  Inside an image rows are ordered patch-major; any bijection is valid because every output
-// address is computed from (b, y, x).
-__device__ __forceinline__ void row_to_pixel(int m, int HoWo, int Wo, int psh, int& b, int& oy, int& ox) {
-    b = m / HoWo;
-    const int rem = m - b * HoWo;
-    const int t = rem >> (2 * psh), in = rem & ((1 << (2 * psh)) - 1);
-    const int tpr = Wo >> psh, ty = t / tpr, tx = t - ty * tpr;
-    oy = (ty << psh) + (in >> psh);
-    ox = (tx << psh) + (in & ((1 << psh) - 1));
-}
-
-__device__ __forceinline__ int reflect_idx(int i, int n) {
-    i = (i < 0) ? -i : i;
-    return (i >= n) ? (2 * n - 2 - i) : i;
-}
-
-// 8 fp32 values -> split-fp16 group: out_hi = fp16(v), out_lo = fp16((v - hi) * 2^11)
-__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const _Float16 h = (_Float16)v[q];
-        hi[q] = h;
-        lo[q] = (_Float16)((v[q] - (float)h) * 2048.0f);
-    }
-}
-__device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
+#include "conv_common.h"
 
 // 16 zero bytes in global memory: the source of a direct-to-LDS load whose im2col element is padding / out of range
 __device__ __attribute__((aligned(16))) float g_zero16_conv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -90,12 +51,6 @@ __device__ __forceinline__ const float* psel(bool c, const float* p, const float
     const unsigned long long m = 0ull - (unsigned long long)c;
     return (const float*)(((unsigned long long)p & m) | ((unsigned long long)q & ~m));
 }
-
-// LDS operand image: [rows][32 dwords] (one 128-byte K chunk per row), written by global_load_lds_dwordx4 — 64 lanes x 16 B =
-// 8 consecutive rows per wave instruction, lane-linear, so no padding is possible.  Bank conflicts are removed by an XOR
-// swizzle applied on the SOURCE side (which 16-byte piece of the row a lane fetches) and on the read side:
-// physical piece = logical piece ^ ((row >> 1) & 7)  => the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte slots.
-__device__ __forceinline__ int lds_piece(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
 
 // K-walk modes of conv_tile
 //   KW_GENERIC  any geometry: tap / channel / source recomputed per chunk with divides (3x3 with C % 32 != 0, e.g. an 8-channel input)
@@ -601,13 +556,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     }
 }
 
-// XCD-aware tile id: hardware places block id on XCD id%8; give each XCD a contiguous run of logical tiles
-__device__ __forceinline__ int xcd_logical(int id, int nblk) {
-    const int xcd = id & 7, slot = id >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
@@ -662,6 +610,10 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC>(a, st);
 }
 
+// conv_pp.hip: 8-wave ping-pong kernel (256 x 128 tile, 3-stage ring) for the deep split-fp16 3x3 layers
+bool smirk_conv_pp_eligible(const ConvArgs& a);
+int smirk_conv_pp_launch(const ConvArgs& a, hipStream_t st);
+
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
 bool smirk_conv3x3_patch_eligible(const SmirkConvDesc* d, bool has_residual);
 int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
@@ -698,6 +650,7 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
     if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
+    if (split && smirk_conv_pp_eligible(a)) return smirk_conv_pp_launch(a, st);
     if (split) {
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);

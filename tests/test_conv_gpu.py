@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TOL = 3e-5      # abs on O(1..10) outputs: both arithmetic modes are fp32-class
 
 
-def _run(B, H, C0, C1, Cout, k=3, reflect=False, seed=0):
+def _run(B, H, C0, C1, Cout, k=3, reflect=False, seed=0, residual=False, relu=True, only_split=False):
     from smirk_amd import _lib as L
     from smirk_amd.smirk_generator import _split16, split16_to_float
     lib, dev = L.lib(), torch.device("cuda")
@@ -24,15 +24,23 @@ def _run(B, H, C0, C1, Cout, k=3, reflect=False, seed=0):
     xp = xin.permute(0, 3, 1, 2).double()
     if k == 3:
         xp = F.pad(xp, (1, 1, 1, 1), mode="reflect" if reflect else "constant")
-    ref = F.relu(F.conv2d(xp, wt) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    ref = (F.conv2d(xp, wt) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    res = torch.randn(B, H, H, Cout, generator=g) if residual else None
+    if residual:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
     d = L.SmirkConvDesc()
     d.B, d.H, d.W, d.C0, d.C1, d.Cout, d.KH, d.KW, d.stride = B, H, H, C0, C1, Cout, k, k, 1
     d.pad_t = d.pad_l = (k - 1) // 2
-    d.Ho, d.Wo, d.pad_mode, d.act, d.out_mode = H, H, (L.PAD_REFLECT if reflect else L.PAD_ZERO), L.ACT_RELU, L.OUT_NHWC
+    d.Ho, d.Wo, d.pad_mode, d.out_mode = H, H, (L.PAD_REFLECT if reflect else L.PAD_ZERO), L.OUT_NHWC
+    d.act = L.ACT_RELU if relu else L.ACT_NONE
     P = L.ptr
     x0d, x1d, wd, scd, shd = x0.to(dev), (x1.to(dev) if C1 else None), w.to(dev), sc.to(dev), sh.to(dev)
     o32 = torch.empty(B, H, H, Cout, device=dev)
-    L.check(lib.smirk_conv_igemm_f32(d, P(x0d), P(x1d, allow_none=True), P(wd), P(scd), P(shd), None, P(o32), L.stream_ptr()))
+    resd = res.to(dev) if residual else None
+    if not only_split:
+        L.check(lib.smirk_conv_igemm_f32(d, P(x0d), P(x1d, allow_none=True), P(wd), P(scd), P(shd), P(resd, allow_none=True), P(o32), L.stream_ptr()))
 
     def split(t):
         o = torch.empty_like(t)
@@ -40,8 +48,11 @@ def _run(B, H, C0, C1, Cout, k=3, reflect=False, seed=0):
         return o
     s0, s1, ws = split(x0d), (split(x1d) if C1 else None), _split16(wd)
     os_ = torch.empty(B, H, H, Cout, device=dev)
-    L.check(lib.smirk_conv_igemm_f16x3(d, P(s0), P(s1, allow_none=True), P(ws), P(scd), P(shd), None, P(os_), L.stream_ptr()))
+    rs = split(resd) if residual else None
+    L.check(lib.smirk_conv_igemm_f16x3(d, P(s0), P(s1, allow_none=True), P(ws), P(scd), P(shd), P(rs, allow_none=True), P(os_), L.stream_ptr()))
     torch.cuda.synchronize()
+    if only_split:
+        return ref, os_
     return ref, o32.cpu().double(), split16_to_float(os_).cpu().double()
 
 
@@ -64,6 +75,29 @@ def test_conv_reflect_and_1x1():
     assert (o32 - ref).abs().max().item() < TOL and (os_ - ref).abs().max().item() < TOL
     ref, o32, os_ = _run(2, 28, 40, 0, 72, k=1)                     # encoder-style pointwise conv, K = 40 (partial chunk)
     assert (o32 - ref).abs().max().item() < TOL and (os_ - ref).abs().max().item() < TOL
+
+
+# shapes served by the 8-wave ping-pong kernel (conv_pp.hip: 3x3, power-of-two channel counts >= 32, Cout % 128 == 0, M >= 1024): the generator's
+# 56^2 / 28^2 / 14^2 layers incl. the decoder's two-source convs, the reflect-padded residual blocks (residual add, no ReLU) and ragged last tiles
+PP_CASES = [dict(B=4, H=56, C0=64, C1=0, Cout=128), dict(B=2, H=56, C0=128, C1=128, Cout=128), dict(B=5, H=28, C0=256, C1=256, Cout=256),
+            dict(B=9, H=14, C0=512, C1=0, Cout=512, reflect=True, residual=True, relu=False), dict(B=7, H=14, C0=256, C1=0, Cout=512),
+            dict(B=3, H=28, C0=128, C1=0, Cout=256, reflect=True)]
+
+
+@pytest.mark.parametrize("cfg", PP_CASES)
+def test_conv_pingpong_kernel_matches_fp64_and_the_128x128_kernel_bitwise(cfg):
+    """conv_pp_kernel walks K in the same order and issues the same MFMA sequence per accumulator as conv_igemm_kernel's channel-major walk:
+    within tolerance of torch fp64, and BIT-IDENTICAL to the kernel it replaces (SMIRK_IGEMM_PP=0)."""
+    import os
+    from smirk_amd.smirk_generator import split16_to_float
+    ref, a = _run(**cfg, only_split=True)
+    os.environ["SMIRK_IGEMM_PP"] = "0"
+    try:
+        _, b = _run(**cfg, only_split=True)
+    finally:
+        del os.environ["SMIRK_IGEMM_PP"]
+    assert (split16_to_float(a).cpu().double() - ref).abs().max().item() < TOL
+    assert torch.equal(a, b)
 
 
 def test_split16_roundtrip_is_fp32_class():

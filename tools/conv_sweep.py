@@ -50,6 +50,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--only", default="", help="substring filter on the layer name")
+    ap.add_argument("--ab-pp", action="store_true", help="time every layer twice: SMIRK_IGEMM_PP=0 (128x128 kernel) and default (ping-pong kernel where eligible)")
     a = ap.parse_args()
     B = a.batch
     layers = [  # name, H, C0, C1, Cout, k, convt, reflect, count in the generator
@@ -65,7 +66,13 @@ if __name__ == "__main__":
     for name, H, C0, C1, Cout, k, convt, refl, cnt in layers:
         if a.only and a.only not in name:
             continue
+        extra = ""
+        if a.ab_pp:
+            os.environ["SMIRK_IGEMM_PP"] = "0"
+            ms0, tf0 = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
+            del os.environ["SMIRK_IGEMM_PP"]
+            extra = f"   [PP off: {ms0:8.3f} ms {tf0:7.1f} TFLOP/s]"
         ms, tf = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
         tot_ms += ms * cnt; tot_fl += tf * ms * cnt
-        print(f"{name:14s} H={H:3d} Cin={C0 + C1:4d} Cout={Cout:4d} k={k} convT={convt} x{cnt:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s")
+        print(f"{name:14s} H={H:3d} Cin={C0 + C1:4d} Cout={Cout:4d} k={k} convT={convt} x{cnt:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s{extra}", flush=True)
     print(f"generator igemm total: {tot_ms:.2f} ms for B={B}  ->  {tot_fl / tot_ms:.1f} TFLOP/s average, {B / tot_ms * 1e3:.0f} faces/s bound")
