@@ -48,6 +48,10 @@ __device__ __forceinline__ int pp_lds(int row, int stage, int piece) {
     return (((row >> 3) * PP_NSTAGE + stage) << 8) + ((row & 7) << 5) + ((piece ^ ((row >> 1) & 7)) << 2);
 }
 
+// NL: how many of a wave's 6 DMA instructions per chunk are issued in the load phase; the other 6 - NL are issued in the matrix phase, one after
+// every fourth MFMA (an LDS-DMA costs its wave ~60 issue cycles among MFMAs but 100-185 in a phase that also carries 16 ds_read_b128:
+// MI355X_MICROARCH.md price list), so that neither phase of the ping-pong is the long pole.
+template <int NL>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pp_smem[];
     float* smem = pp_smem;
@@ -94,12 +98,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     const int twoW = 2 * d.W;
     const unsigned col16 = (unsigned)col4 * 16u;
 
-    // DMA of chunk (cc, TAP) into ring stage ST: 4 A pieces + 2 B pieces per wave (1 KiB each)
-    auto issue = [&](int cc, auto tapc, auto stc) {
-        constexpr int TAP = decltype(tapc)::value, ST = decltype(stc)::value, KY = TAP / 3, KX = TAP % 3;
+    // DMA of chunk (cc, TAP) into ring stage ST: 4 A pieces + 2 B pieces per wave (1 KiB each).  `prep` computes the four per-lane A offsets (VALU,
+    // load phase), `piece` issues DMA instruction k (0-3: A rows 8 swave + 64 k ..., 4-5: B) — so the issue points can be spread over both phases.
+    unsigned vo[4];
+    int dma_sa = 0, dma_sw = 0, dma_s1 = 0;
+    auto prep = [&](int cc, auto tapc) {
+        constexpr int TAP = decltype(tapc)::value, KY = TAP / 3, KX = TAP % 3;
         const int c0 = cc * CV_BK;
         const bool s1 = c0 >= d.C0;
-        const int sh = s1 ? sh1 : sh0, sa = (s1 ? c0 - d.C0 : c0) * 4, sw = (TAP * a.Cin + c0) * 4;
+        const int sh = s1 ? sh1 : sh0;
+        dma_s1 = s1; dma_sa = (s1 ? c0 - d.C0 : c0) * 4; dma_sw = (TAP * a.Cin + c0) * 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             int px = pixc[p];
@@ -112,14 +120,32 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
             if constexpr (KX == 0) px += (int)((f >> 2) & 1u) * 2 - 1;
             if constexpr (KX == 2) px += 1 - (int)((f >> 3) & 1u) * 2;
             const unsigned inval = (((f >> (4 + KY)) & (f >> (7 + KX))) & 1u) ^ 1u;    // 1: this tap of this row lies in the zero padding
-            const unsigned vo = (((unsigned)px << sh) + col16) | (inval << 31);         // bit 31 set => beyond num_records => the DMA writes zeros
-            float* dst = smem + (((swave + 8 * p) * PP_NSTAGE + ST) << 8);           // block swave + 8p (rows 8 swave + 64 p ...), stage ST
-            if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (pp_lptr_t)dst, 16, vo, sa, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (pp_lptr_t)dst, 16, vo, sa, 0, 0);
+            vo[p] = (((unsigned)px << sh) + col16) | (inval << 31);                    // bit 31 set => beyond num_records => the DMA writes zeros
         }
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (pp_lptr_t)(smem + (((PP_BM / 8 + swave + 8 * p) * PP_NSTAGE + ST) << 8)), 16, voffB[p], sw, 0, 0);
+    };
+    auto piece = [&](auto kc, auto stc) {
+        constexpr int KP = decltype(kc)::value, ST = decltype(stc)::value;
+        if constexpr (KP < 4) {
+            float* dst = smem + (((swave + 8 * KP) * PP_NSTAGE + ST) << 8);          // block swave + 8 KP (rows 8 swave + 64 KP ...), stage ST
+            if (dma_s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (pp_lptr_t)dst, 16, vo[KP], dma_sa, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (pp_lptr_t)dst, 16, vo[KP], dma_sa, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (pp_lptr_t)(smem + (((PP_BM / 8 + swave + 8 * (KP - 4)) * PP_NSTAGE + ST) << 8)), 16,
+                                                     voffB[KP - 4], dma_sw, 0, 0);
+        }
+    };
+    auto pieces = [&](auto loc, auto hic, auto stc) {             // DMA instructions [LO, HI)
+        constexpr int LO = decltype(loc)::value, HI = decltype(hic)::value;
+        if constexpr (LO <= 0 && 0 < HI) piece(std::integral_constant<int, 0>{}, stc);
+        if constexpr (LO <= 1 && 1 < HI) piece(std::integral_constant<int, 1>{}, stc);
+        if constexpr (LO <= 2 && 2 < HI) piece(std::integral_constant<int, 2>{}, stc);
+        if constexpr (LO <= 3 && 3 < HI) piece(std::integral_constant<int, 3>{}, stc);
+        if constexpr (LO <= 4 && 4 < HI) piece(std::integral_constant<int, 4>{}, stc);
+        if constexpr (LO <= 5 && 5 < HI) piece(std::integral_constant<int, 5>{}, stc);
+    };
+    auto issue = [&](int cc, auto tapc, auto stc) {
+        prep(cc, tapc);
+        pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, stc);
     };
 
     f32x16 acc0[2][2], acc1[2][2];
@@ -153,28 +179,58 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
         // the chunk two ahead; past the end of K the (clamped) last channel chunk is fetched again into a stage nobody reads any more — two
         // wasted chunk loads per tile instead of a branch (and its duplicated code) in seven of nine loop bodies
         constexpr int T2 = (TAP + 2) % 9, S2 = T2 % 3;
-        issue(min(cc + (TAP + 2 >= 9 ? 1 : 0), ncc - 1), std::integral_constant<int, T2>{}, std::integral_constant<int, S2>{});
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");       // the next chunk has landed (this wave's share); fragment reads done
+        prep(min(cc + (TAP + 2 >= 9 ? 1 : 0), ncc - 1), std::integral_constant<int, T2>{});
+        pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NL>{}, std::integral_constant<int, S2>{});
+        // everything issued before these NL instructions has landed: the whole next chunk (this wave's share); fragment reads done
+        if constexpr (NL == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NL == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NL == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- matrix phase: 24 MFMAs, operands already in registers; dependent accumulations are four instructions apart ----------------------
         __builtin_amdgcn_s_setprio(1);
+        constexpr int NM = 6 - NL;                                     // DMA instructions left for this phase: one after every fourth MFMA
+        auto mm_dma = [&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            if constexpr (G < NM) {
+                __builtin_amdgcn_sched_barrier(0);
+                piece(std::integral_constant<int, NL + G>{}, std::integral_constant<int, S2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], acc0[i][j], 0, 0, 0);
+        mm_dma(std::integral_constant<int, 0>{});
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc0[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], acc1[i][j], 0, 0, 0);
+        mm_dma(std::integral_constant<int, 1>{});
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc1[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], acc1[i][j], 0, 0, 0);
+        mm_dma(std::integral_constant<int, 2>{});
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc1[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], acc0[i][j], 0, 0, 0);
+        mm_dma(std::integral_constant<int, 3>{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], acc1[i][j], 0, 0, 0);
+        mm_dma(std::integral_constant<int, 4>{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], acc1[i][j], 0, 0, 0);
+        mm_dma(std::integral_constant<int, 5>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -258,21 +314,38 @@ bool smirk_conv_pp_eligible(const ConvArgs& a) {
     if (a.N % PP_BN || a.N < PP_BN) return false;
     const long long b0 = (long long)d.B * d.H * d.W * d.C0 * 4, b1 = (long long)d.B * d.H * d.W * d.C1 * 4, bw = (long long)a.N * a.K * 4;
     if (b0 >= (1ll << 31) || b1 >= (1ll << 31) || bw >= (1ll << 31)) return false;
+    // Measured per layer at B = 128 (tools/conv_sweep.py --ab-pp, profiles/r02_conv_sweep_pp.txt): 14x14 layers 0.320-0.325 -> 0.277-0.279 ms
+    // (K = 2304 / 4608: 72 / 144 chunks per tile amortise the exposed prologue + epilogue of the single workgroup per CU), 28x28 and 56x56
+    // layers 1-9 % SLOWER (36-72 chunks per tile; the 128x128 kernel hides one workgroup's epilogue behind its co-resident twin's main
+    // loop).  SMIRK_IGEMM_PP=all lifts the restriction for experiments.
+    const bool all = env && env[0] == 'a';
+    if (!all && (long long)d.Ho * d.Wo > 256) return false;
     return a.M >= 4 * PP_BM;                                          // tiny problems stay on the 128-row tiles
 }
 
 int smirk_conv_pp_launch(const ConvArgs& a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess) return SMIRK_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)conv_pp_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess)
+            return SMIRK_ERR_LAUNCH;
         attr_done = true;
     }
+    const char* nle = getenv("SMIRK_PP_NL");                         // tuning switch: DMA instructions issued in the load phase (default 3)
+    const int nl = nle ? atoi(nle) : 3;
     const int ntm = (a.M + PP_BM - 1) / PP_BM, ntn = a.N / PP_BN;
     if (g_smirk_prof_on) {
         const double px = (double)a.d.B * a.d.H * a.d.W;
-        smirk_prof_next("conv_pp_kernel<256,128,8w,3stage>", 2.0 * a.M * a.N * a.K,
+        char nm[64];
+        snprintf(nm, sizeof(nm), "conv_pp_kernel<%d>[256x128,8w,3stage]", nl == 6 ? 6 : nl == 0 ? 0 : nl == 2 ? 2 : 3);
+        smirk_prof_next(nm, 2.0 * a.M * a.N * a.K,
                         4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
     }
-    SMIRK_LAUNCH(conv_pp_kernel, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
+    if (nl == 6) SMIRK_LAUNCH(conv_pp_kernel<6>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
+    else if (nl == 0) SMIRK_LAUNCH(conv_pp_kernel<0>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
+    else if (nl == 2) SMIRK_LAUNCH(conv_pp_kernel<2>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
+    else SMIRK_LAUNCH(conv_pp_kernel<3>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
     return smirk_launch_status();
 }
