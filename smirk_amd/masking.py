@@ -66,11 +66,19 @@ def masking(img, mask, extra_points, wr=15, rendered_mask=None, extra_noise=True
     img, mask = L.as_f32c(img), L.as_f32c(mask)
     extra_points = None if extra_points is None else L.as_f32c(extra_points)
     B, C, H, W = img.shape
+    # the reference's own call site passes a 3-D hull mask [1,H,W] (demo.py:161, demo_video.py): F.max_pool2d's unbatched mode plus
+    # broadcasting make that work there; normalise to [B or 1, 1, H, W] here
+    if mask.dim() == 3:
+        mask = mask.unsqueeze(0) if mask.shape[0] == 1 else mask.unsqueeze(1)          # [1,H,W] -> [1,1,H,W] (broadcast over the batch); [B,H,W] -> [B,1,H,W]
+    if rendered_mask is not None and rendered_mask.dim() == 3:
+        rendered_mask = rendered_mask.unsqueeze(0) if rendered_mask.shape[0] == 1 else rendered_mask.unsqueeze(1)
     lib, st = L.lib(), L.stream_ptr()
     if mask.shape[0] != B:
         mask = mask.expand(B, -1, -1, -1).contiguous()
     mask_d = _maxpool_sq(mask, wr, complement=3)                             # 1 - maxpool(1 - mask, 2wr+1)
     rm = None if rendered_mask is None else L.as_f32c(rendered_mask)
+    if rm is not None and rm.shape[0] != B:
+        rm = rm.expand(B, -1, -1, -1).contiguous()
     keep = None
     if random_mask > 0 or _random_field is not None:
         if _random_field is None:

@@ -161,6 +161,10 @@ class Renderer(nn.Module):
             o = torch.empty(B, lm.shape[1], 2, device=dev)
             L.check(lib.smirk_project_landmarks(P(lm), P(cam), B, lm.shape[1], P(o), L.stream_ptr()))
             proj.append(o)
+        if self.render_full_head:
+            # reference quirk (renderer.py:141): render() adds the near-plane shift `z += 10` IN PLACE; with the face sub-mesh that hits
+            # an advanced-index copy, in full-head mode it hits the very tensor forward() returns as 'transformed_vertices'
+            tv[..., 2] += 10
         aux = dict(pix_to_face=p2f, bary=bary, zbuf=zbuf, normals=nrm) if want_aux else p2f
         return img, tv, proj, aux
 

@@ -87,11 +87,13 @@ class VideoPipeline:
     def _submit(self, slot, frames, lmks):
         n = len(frames)
         Hv, Wv = frames[0].shape[:2]
-        has_lmk = lmks[0] is not None
-        if (self.crop or self.use_gen) and not all(l is not None for l in lmks):
+        need_lmk = self.crop or self.use_gen
+        if need_lmk and not all(l is not None for l in lmks):
             # demo_video.py:116-119,177-179: the script exits when mediapipe finds nothing and it has to crop / build the hull mask
             raise ValueError("landmarks are required for every frame when crop / use_smirk_generator is set")
-        L_pts = int(np.asarray(lmks[0]).shape[0]) if has_lmk else 0
+        # without crop / generator the landmarks are never consumed and the reference tolerates frames where mediapipe found nothing
+        # (demo_video.py:110-119): nothing is staged then, whatever mix of None / arrays the batch holds
+        L_pts = int(np.asarray(lmks[0]).shape[0]) if need_lmk else 0
         self._prepare(slot, Hv, Wv, L_pts)
         hf = slot.h_frames.numpy()
         for i, f in enumerate(frames):
@@ -107,7 +109,7 @@ class VideoPipeline:
                 hm[i, 1] = T[:2].reshape(6)                     # frame (col,row) -> crop (x,y): warp(rendered, tform)
                 ck = (T @ np.hstack([kpt, np.ones([kpt.shape[0], 1])]).T).T[:, :2]                 # demo_video.py:126-127
             else:
-                ck = None if lmks[i] is None else np.asarray(lmks[i], np.float64)[..., :2]
+                ck = np.asarray(lmks[i], np.float64)[..., :2] if need_lmk else None
             if ck is not None:
                 hl[i] = ck.astype(np.int32)                     # create_mask's landmarks.astype(np.int32)
         for i in range(n, self.N):                              # ragged last batch: replicate the last frame, dropped on output

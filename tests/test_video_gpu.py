@@ -187,3 +187,17 @@ def test_video_pipeline_with_generator_and_requirements(modules):
         list(vp.run(frames, [None] * 6))                       # demo_video.py:177-179: no landmarks -> cannot build the hull mask
     with pytest.raises(ValueError):
         VideoPipeline(enc, fl, rn, use_smirk_generator=True)
+
+
+def test_video_pipeline_tolerates_missing_landmarks_without_crop_or_generator(modules):
+    """demo_video.py:110-119: without --crop / --use_smirk_generator the landmarks are never consumed, so frames where mediapipe found nothing
+    (None), in any mix with frames that have landmarks, must stream through unchanged."""
+    from smirk_amd import VideoPipeline
+    enc, fl, rn, _, _ = modules
+    frames, lmks = _frames(6, 240, 320, seed=4), _landmarks(6, 240, 320, seed=4)
+    ref = list(VideoPipeline(enc, fl, rn, batch_size=4).run(frames, lmks))
+    mixed = [None, lmks[1], None, None, lmks[4], lmks[5]]
+    got = list(VideoPipeline(enc, fl, rn, batch_size=4).run(frames, mixed))
+    assert len(got) == 6
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
