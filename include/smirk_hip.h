@@ -201,6 +201,10 @@ int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0, const void
 /* fp32 <-> split16 conversion of n_elems values (n_elems % 8 == 0; groups of 8 consecutive values). */
 int smirk_f32_to_split16(const float* in, void* out, size_t n_elems, void* stream);
 int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, void* stream);
+/* Debugging aid ($SMIRK_F16X3_RANGE_CHECK in the Python host): audits a split16 tensor for values the format cannot carry — counts[0] += number of
+ * elements that are non-finite or have |x| >= limit (the fp16 `hi` half saturates at 65504), counts[1] = max(counts[1], bits of the largest finite |x|).
+ * counts: two zero-initialised uint32 on the device. */
+int smirk_split16_range_check(const void* in, size_t n_elems, float limit, uint32_t* counts, void* stream);
 /* split16 versions of the generator's streaming ops (smirk_generator.py:13-19,47-49,76; smirk_trainer.py:94): max-pool, fused
  * cat(a[B,Ca,H,W], b[B,Cb,H,W]) + NCHW->NHWC + split (Ca+Cb <= 8, zero-padded to one 8-channel group), final 1x1 conv + sigmoid. */
 int smirk_maxpool2x2_split16(const void* in, void* out, int B, int H, int W, int C, void* stream);

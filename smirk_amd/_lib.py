@@ -109,6 +109,7 @@ _SIGS = {
     "smirk_f32_to_split16": (_i, [_p, _p, _sz, _p]),
     "smirk_split16_to_f32": (_i, [_p, _p, _sz, _p]),
     "smirk_maxpool2x2_split16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "smirk_split16_range_check": (_i, [_p, _sz, C.c_float, _p, _p]),
     "smirk_pack_generator_input_split16": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _p]),
     "smirk_conv1x1_sigmoid_nchw_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_maxpool2x2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -723,6 +723,32 @@ extern "C" int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, 
     return smirk_launch_status();
 }
 
+static unsigned grid_for(size_t total, unsigned cap);
+
+// Range audit of a split16 tensor (debugging aid behind $SMIRK_F16X3_RANGE_CHECK): the split-fp16 format carries |x| < 65504 only (hi is an fp16);
+// counts the values whose hi half is non-finite or whose magnitude reaches `limit`.  counts[0] += offenders, counts[1] = max |x| seen (as float bits).
+__global__ __launch_bounds__(256) void split16_range_kernel(const float* __restrict__ in, size_t ng, float limit, unsigned* __restrict__ counts) {
+    unsigned bad = 0;
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += (size_t)gridDim.x * blockDim.x) {
+        const half8 hi = *(const half8*)(in + i * 8), lo = *(const half8*)(in + i * 8 + 4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float v = fabsf(join1(hi[q], lo[q]));
+            if (!(v < limit)) ++bad;                                  // also catches NaN
+            else mx = fmaxf(mx, v);
+        }
+    }
+    if (bad) atomicAdd(counts, bad);
+    atomicMax(counts + 1, __float_as_uint(mx));
+}
+
+extern "C" int smirk_split16_range_check(const void* in, size_t n_elems, float limit, uint32_t* counts, void* stream) {
+    if (!in || !counts || n_elems % 8) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(split16_range_kernel, dim3(grid_for(n_elems / 8, 4096)), dim3(256), 0, (hipStream_t)stream, (const float*)in, n_elems / 8, limit, counts);
+    return smirk_launch_status();
+}
+
 // 2x2/2 max pool on split tensors: the winning element's (hi, lo) pair is copied unchanged (exact).
 __global__ __launch_bounds__(256) void maxpool2x2_split_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
                                                                int W, int G) {

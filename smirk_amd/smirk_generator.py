@@ -178,6 +178,9 @@ class SmirkGenerator(nn.Module):
         dev = a.device
         out = torch.empty(B, self.out_channels, H, W, device=dev)
         tp = None
+        audit = self._split and os.environ.get("SMIRK_F16X3_RANGE_CHECK")
+        if audit and taps is None:
+            taps = {}
         if taps is not None:
             f = self.features
             shapes = [(H >> l, W >> l, f << l) for l in range(5)] + [(H >> 4, W >> 4, f << 4)] + [(H >> l, W >> l, f << l) for l in (3, 2, 1, 0)]
@@ -188,9 +191,27 @@ class SmirkGenerator(nn.Module):
         ws = self._ws.get(nws, dev)
         L.check(lib.smirk_generator_forward(w, L.ptr(a), Ca, L.ptr(b, allow_none=True), Cb, L.ptr(out), B, H, W, tp, L.ptr(ws, torch.uint8), nws,
                                             L.stream_ptr()))
+        if audit:
+            self._range_audit(taps, float(audit) if audit not in ("1", "true") else 6.0e4)
         # the reference back-propagates through the generator (smirk_trainer.py:94-104); this forward has no backward yet, so make any
         # attempt to do so fail loudly instead of handing the caller zero / missing gradients
         return L.loud_cut("smirk_amd.SmirkGenerator.forward", out, srcs + list(self.parameters()))
+
+    def _range_audit(self, taps, limit):
+        """$SMIRK_F16X3_RANGE_CHECK=1 (or a limit): the split-fp16 format saturates at |x| = 65504 — BatchNorm'd activations of a trained network are
+        O(1..100), but a badly scaled checkpoint would turn into inf / NaN silently.  Audits the ten block outputs of this forward (taps disable the
+        fused tail, so this is a debugging mode) and raises naming the first offending block."""
+        lib, st = L.lib(), L.stream_ptr()
+        counts = torch.zeros(len(self.TAPS), 2, dtype=torch.int32, device=next(iter(taps.values())).device)
+        for i, k in enumerate(self.TAPS):
+            t = taps[k]
+            L.check(lib.smirk_split16_range_check(L.ptr(t), t.numel(), limit, L.ptr(counts[i], torch.int32), st))
+        c = counts.cpu()
+        for i, k in enumerate(self.TAPS):
+            if int(c[i, 0]):
+                mx = float(c[i, 1:2].view(torch.float32))
+                raise L.SmirkHipError(f"f16x3 range check: {int(c[i, 0])} activations of block '{k}' are non-finite or >= {limit:g} in magnitude "
+                                      f"(largest finite |x| = {mx:.4g}); the split-fp16 mode cannot carry them — use precision = 'f32'")
 
     def forward_pair(self, rendered, masked, _taps=None):
         """generator(torch.cat([rendered, masked], 1)) without materialising the concatenation (smirk_trainer.py:94, demo.py:167)."""

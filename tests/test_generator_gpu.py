@@ -78,3 +78,22 @@ def test_generator_train_mode_raises(gen):
             m(torch.zeros(1, 6, 32, 32).cuda())
     finally:
         m.eval()
+
+
+def test_f16x3_range_check_flags_a_badly_scaled_checkpoint(monkeypatch):
+    """$SMIRK_F16X3_RANGE_CHECK: activations beyond the fp16 range of the split format must be reported per block, not propagate as inf/NaN."""
+    from smirk_amd import SmirkGenerator, SmirkHipError
+    sd = G.synth_state_dict()
+    m = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = A.synth_generator_input(1, seed=5).cuda()
+    monkeypatch.setenv("SMIRK_F16X3_RANGE_CHECK", "1")
+    with torch.no_grad():
+        y = m(x)                                                   # a calibrated network passes the audit
+        assert torch.isfinite(y).all()
+        m.encoder3.enc3norm2.weight.mul_(3e5)                      # blow one block's activations past 65504
+        with pytest.raises(SmirkHipError, match="enc3"):
+            m(x)
+        m.precision = "f32"                                        # the exact-fp32 mode carries them (no audit needed)
+        assert torch.isfinite(m(x)).all()
