@@ -65,6 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--micro-batch", type=int, default=MICRO_BATCH)
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run each micro-batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
+    ap.add_argument("--generator-streams", type=int, default=1, help="generator stages of consecutive micro-batches alternate over this many streams")
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
     ap.add_argument("--cpu-faces", type=int, default=24, help="sample size of the CPU baseline (0 = skip)")
@@ -299,8 +300,6 @@ class FullWorkload(Workload):
         self.B = per_rank_batch(args, world)
         mb = min(args.micro_batch, self.B)
         self.slices = [(i, min(i + mb, self.B)) for i in range(0, self.B, mb)]
-        if world > 1 and len({hi - lo for lo, hi in self.slices}) != 1:
-            raise SystemExit("multi-GPU all-gather needs equal micro-batches: choose a per-GPU batch that is a multiple of --micro-batch")
         B = self.B
         # a distinct seeded shard per rank, resident in HBM before the timed region; generated in chunks to bound host memory
         self.img = torch.cat([synth.synth_images(hi - lo, seed=1000 + 97 * rank + lo).to(dev) for lo, hi in self.slices])
@@ -312,7 +311,7 @@ class FullWorkload(Workload):
         assert self.img.shape[0] == B
         self.given = args.given_masked
         self.gather = OutputGatherer()
-        self.runner = OverlappedPipeline(self.pipe) if args.overlap else None
+        self.runner = OverlappedPipeline(self.pipe, generator_streams=args.generator_streams) if args.overlap else None
 
     def _kw(self, lo, hi):
         return dict(masked_img=self.masked[lo:hi]) if self.given else dict(hull_mask=self.hull[lo:hi])
@@ -335,8 +334,10 @@ class FullWorkload(Workload):
 
     def drain(self):
         if self.runner is not None:
-            done = self.runner.flush()
-            if done is not None:
+            while True:
+                done = self.runner.flush()
+                if done is None:
+                    break
                 self._finish(done)
         self.gather.wait()
 
@@ -430,7 +431,7 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
     dom = max(per, key=lambda k: per[k][2])
     fl, by, tm, n = per[dom]
     split = ",true," in dom or dom.endswith("true>")
-    gemm = dom.startswith(("conv_igemm_kernel", "flame_blend_skin", "flame_bwd"))
+    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd"))
     traffic = None
     if traffic_table:
         t = traffic_table.get(dom) or traffic_table.get(dom.replace(", ", ","))
@@ -581,7 +582,7 @@ def main():
                        "weights": "random-init (He) reference architecture, encoder heads rescaled to the trained network's parameter ranges; no checkpoint offline; outputs asserted finite",
                        **({"masking": "given masked image" if args.given_masked else
                            "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",
-                           "schedule": "2-stream software pipeline: generator(micro-batch i) || encode+FLAME+render(micro-batch i+1)" if args.overlap else "serial stages"}
+                           "schedule": (f"software pipeline: generator(micro-batch i) on {args.generator_streams} stream(s) || encode+FLAME+render(micro-batch i+1)" if args.overlap else "serial stages")}
                           if args.workload == "full" else {})},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "path_tflops_per_gpu": value / world * flop_face / 1e12,

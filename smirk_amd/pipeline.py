@@ -52,45 +52,66 @@ class SmirkPipeline:
 
 
 class OverlappedPipeline:
-    """Software-pipelines consecutive, independent frame batches over two HIP streams: the latency/bandwidth-bound front
-    (encode -> FLAME -> render) of batch i+1 runs concurrently with the MFMA-bound generator of batch i, so the matrix cores and the
-    memory system are both kept busy.  Results are identical to SmirkPipeline.__call__ (same kernels, same inputs); only the
-    interleaving on the GPU changes.
+    """Software-pipelines consecutive, independent frame batches over HIP streams: the latency/bandwidth-bound front (encode -> FLAME -> render)
+    of batch i+1 runs concurrently with the MFMA-bound generator of batch i, so the matrix cores and the memory system are both kept busy.
+    With `generator_streams=2` consecutive batches' generators additionally alternate between two streams, so that the partially filled last
+    round of workgroups of one batch's deep layers (784 / 392 tiles on 256 CUs) and its HBM-bound 224x224 layers overlap with the other batch's
+    kernels.  Results are identical to SmirkPipeline.__call__ (same kernels, same inputs); only the interleaving on the GPU changes.
 
         run = OverlappedPipeline(pipe)
         for img, masked in batches:
-            done = run.submit(img, masked)      # -> outputs of the PREVIOUS batch (None the first time)
-        last = run.flush()
+            done = run.submit(img, masked)      # -> outputs of an EARLIER batch (None while the pipeline fills), in submission order
+        while (last := run.flush()) is not None: ...
     """
+    _STREAMS = {}                                  # per (device, role): streams are created once per process, not per pipeline object
 
-    def __init__(self, pipe):
+    def __init__(self, pipe, generator_streams=1):
         self.pipe = pipe
-        self.front_stream, self.gen_stream = None, None
-        self._pending = None                       # (front outputs, masked, event) of the batch whose generator has not run yet
+        self.n_gen = int(generator_streams)
+        self.front_stream, self.gen_streams = None, None
+        self._waiting = []                         # front done, generator not enqueued yet: (outputs, masked, front-done event)
+        self._running = []                         # generator enqueued: (outputs, generator-done event), oldest first
+        self._count = 0
 
     def _streams(self, device):
-        if self.front_stream is None or self.front_stream.device != device:
-            self.front_stream, self.gen_stream = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        key = (device, self.n_gen)
+        if key not in self._STREAMS:
+            self._STREAMS[key] = (torch.cuda.Stream(device=device), [torch.cuda.Stream(device=device) for _ in range(self.n_gen)])
+        self.front_stream, self.gen_streams = self._STREAMS[key]
+
+    @property
+    def gen_stream(self):
+        return self.gen_streams[0]
 
     @torch.no_grad()
-    def _generate_pending(self):
-        if self._pending is None:
+    def _start_generators(self):
+        """enqueue the generator stage of every batch whose front stages have been enqueued (each on the next generator stream)"""
+        while self._waiting:
+            out, masked, ev = self._waiting.pop(0)
+            gs = self.gen_streams[self._count % self.n_gen]
+            self._count += 1
+            with torch.cuda.stream(gs):
+                gs.wait_event(ev)
+                g = self.pipe.generator
+                if isinstance(masked, tuple):                   # ("hull", img, hull_mask): masking utilities run with the generator stage
+                    _, im, hull = masked
+                    masked = self.pipe.masked_from_hull(im, hull, out)
+                    out['masked_img'] = masked
+                    for t in (out['transformed_vertices'], im, hull):
+                        t.record_stream(gs)
+                out['reconstructed_img'] = g.forward_pair(out['rendered_img'], masked)
+                for t in (out['rendered_img'], masked):
+                    t.record_stream(gs)
+                done = torch.cuda.Event()
+                done.record(gs)
+            self._running.append((out, done))
+
+    def _pop_finished(self, keep):
+        """hand the oldest batch back once more than `keep` generators are in flight"""
+        if len(self._running) <= keep:
             return None
-        out, masked, ev = self._pending
-        self._pending = None
+        out, done = self._running.pop(0)
         caller = torch.cuda.current_stream()
-        with torch.cuda.stream(self.gen_stream):
-            self.gen_stream.wait_event(ev)
-            g = self.pipe.generator
-            if isinstance(masked, tuple):                   # ("hull", img, hull_mask): masking utilities run with the generator stage
-                _, im, hull = masked
-                masked = self.pipe.masked_from_hull(im, hull, out)
-                out['masked_img'] = masked
-            out['reconstructed_img'] = g.forward_pair(out['rendered_img'], masked)
-            for t in (out['rendered_img'], masked):
-                t.record_stream(self.gen_stream)
-            done = torch.cuda.Event()
-            done.record(self.gen_stream)
         caller.wait_event(done)                    # the caller's stream may consume the results
         for t in out.values():
             if torch.is_tensor(t):
@@ -103,7 +124,8 @@ class OverlappedPipeline:
         caller = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(caller)                        # inputs were produced on the caller's stream
-        prev = self._generate_pending()             # enqueue generator(i-1) first: it is the long pole
+        self._start_generators()                    # enqueue generator(i-1) first: it is the long pole
+        prev = self._pop_finished(self.n_gen - 1)
         p = self.pipe
         with torch.cuda.stream(self.front_stream):
             self.front_stream.wait_event(ready)
@@ -116,11 +138,13 @@ class OverlappedPipeline:
             ev = torch.cuda.Event()
             ev.record(self.front_stream)
             img.record_stream(self.front_stream)
-        self._pending = (out, masked_img if hull_mask is None else ("hull", img, hull_mask), ev)
+        self._waiting.append((out, masked_img if hull_mask is None else ("hull", img, hull_mask), ev))
         return prev
 
     def flush(self):
-        return self._generate_pending()
+        """next finished batch in submission order, None when the pipeline is empty"""
+        self._start_generators()
+        return self._pop_finished(0)
 
 
 class OutputGatherer:
@@ -135,7 +159,7 @@ class OutputGatherer:
     def __init__(self, keys=KEYS, group=None):
         self.keys, self.group = tuple(keys), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.bufs, self.pending, self._hold = {}, [], None
+        self.bufs, self.pending, self._hold, self._pool = {}, [], None, {}
 
     def start(self, outputs):
         self._hold = {k: outputs[k].contiguous() for k in self.keys if k in outputs}
@@ -144,9 +168,11 @@ class OutputGatherer:
             return
         for k, t in self._hold.items():
             shape = (self.world * t.shape[0],) + tuple(t.shape[1:])
-            if k not in self.bufs or self.bufs[k].shape != shape or self.bufs[k].device != t.device:
-                self.bufs[k] = torch.empty(shape, dtype=t.dtype, device=t.device)
-            self.pending.append(dist.all_gather_into_tensor(self.bufs[k], t, group=self.group, async_op=True))
+            pool = self._pool.setdefault((k, shape, t.device), None)                # one buffer per distinct micro-batch shape: no allocator churn
+            if pool is None:
+                pool = self._pool[(k, shape, t.device)] = torch.empty(shape, dtype=t.dtype, device=t.device)
+            self.bufs[k] = pool
+            self.pending.append(dist.all_gather_into_tensor(pool, t, group=self.group, async_op=True))
 
     def wait(self):
         for w in self.pending:

@@ -151,8 +151,18 @@ def test_full_pipeline_B128_repeated_serial_and_overlapped(mods):
         if trial % 2 == 0:
             got = [pipe(i, k) for i, k in batches]
         else:
-            run = OverlappedPipeline(pipe)
-            got = [run.submit(i, k) for i, k in batches + batches[:1]][1:] + [run.flush()]
+            run = OverlappedPipeline(pipe, generator_streams=1 + (trial // 2) % 2)       # 1 or 2 generator streams
+            got = [run.submit(i, k) for i, k in batches + batches]
+            while True:
+                o = run.flush()
+                if o is None:
+                    break
+                got.append(o)
+            got = [o for o in got if o is not None]
+            assert len(got) == 4
+            for a, b in zip(got[:2], got[2:]):                                          # the same batch twice through the pipeline
+                for k in keys:
+                    assert torch.equal(a[k], b[k]), (trial, k, "repeat")
             got = got[:2]
         torch.cuda.synchronize()
         for a, b in zip(first, got):
