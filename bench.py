@@ -45,7 +45,8 @@ FLOP_PER_FACE_FLAME = 12.7e6
 PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA = 2500e12          # MI355X_MICROARCH.md: bf16/fp16 dense MFMA peak (the f16x3 kernel issues 3 MFMA-flop per algorithmic flop)
 PEAK_HBM = 8.0e12
-MICRO_BATCH = 128                # frames per pass of the path (activations peak ~8 GB per 128 frames; 32-bit buffer offsets stay valid)
+MICRO_BATCH = 167                # frames per pass of the path: fills whole rounds of 256-row x 128-column tiles on 256 CUs at the 14^2 / 28^2 / 56^2
+                                 # layers (activations ~11 GB per pass; 32-bit buffer offsets stay valid up to 325 frames)
 METRIC = {"full": "faces/sec (encode+FLAME+render+generate) @224x224",
           "infer256": "faces/sec (encode+FLAME+render) @224x224",
           "flame512": "faces/sec (FLAME-only: shape,exp,pose,jaw -> 5023 vertices)"}
@@ -62,7 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=("full", "infer256", "flame512"), default="full")
     ap.add_argument("--global-batch", type=int, default=None, help="frames per step over ALL GPUs (strong scaling; default 1024 / 256 / 512 by workload)")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (weak scaling; overrides --global-batch)")
-    ap.add_argument("--micro-batch", type=int, default=MICRO_BATCH)
+    ap.add_argument("--micro-batch", type=int, default=None,
+                    help="frames per pass of the path (default: 167 when the per-GPU batch is larger — 167 x 196 / 256 x 4 = 511.4 tiles of the deep 14x14\n"
+                         "layers = two full rounds of the 256 CUs, likewise 4 / 8 rounds at 28x28 / 56x56 — else the per-GPU batch)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run each micro-batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
     ap.add_argument("--generator-streams", type=int, default=1, help="generator stages of consecutive micro-batches alternate over this many streams")
@@ -357,7 +360,7 @@ class InferWorkload(Workload):
         enc, flame, rend, _ = build_modules(sandbox, dev, want=("enc", "flame", "rend"))
         self.pipe = SmirkPipeline(enc, flame, rend, None)
         self.B = per_rank_batch(args, world)
-        mb = min(args.micro_batch if args.micro_batch != MICRO_BATCH else 256, self.B)
+        mb = min(256, self.B)
         self.slices = [(i, min(i + mb, self.B)) for i in range(0, self.B, mb)]
         self.img = torch.cat([synth.synth_images(hi - lo, seed=2000 + 97 * rank + lo).to(dev) for lo, hi in self.slices])
 
@@ -430,7 +433,7 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
         return None
     dom = max(per, key=lambda k: per[k][2])
     fl, by, tm, n = per[dom]
-    split = ",true," in dom or dom.endswith("true>")
+    split = ",true," in dom or dom.endswith("true>") or dom.startswith("conv_pp_kernel")      # split-fp16 (f16x3) kernels
     gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd"))
     traffic = None
     if traffic_table:
@@ -459,6 +462,8 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
 
 def main():
     args = parse_args()
+    if args.micro_batch is None:
+        args.micro_batch = MICRO_BATCH
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     import torch
