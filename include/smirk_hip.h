@@ -354,6 +354,42 @@ int smirk_backbone_forward(const SmirkBackboneWeights* w, const float* img, int 
                            void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Training-mode building blocks (BASELINE config 5, generator slice) — what autograd + nn.BatchNorm2d.train() compute inside the reference's
+ * SmirkGenerator after `trainer.train()` (base_trainer.py:108-111; smirk_generator.py:88-119,121-178; smirk_trainer.py:184-332,365-382).
+ * Activations and activation gradients are split16 NHWC ([M = B*H*W][C]); statistics, affine parameters and weight gradients are fp32.
+ * Reductions are two-stage fp64 in a fixed order (bit-reproducible).  Data gradients of convolutions reuse smirk_conv_igemm_f16x3 with the
+ * weights rotated by 180 degrees and Cin <-> Cout swapped (host-side repack), so they have no entry of their own.
+ * ------------------------------------------------------------------------------------------------------------------ */
+size_t smirk_train_reduce_workspace_bytes(int C);
+/* y = [relu]((z - mean_batch) / sqrt(var_batch + eps) * gamma + beta [+ residual]);  saves mean / biased var / invstd for the backward pass and updates
+ * running_mean / running_var (nullable) with `momentum` (running_var takes the unbiased variance), exactly like F.batch_norm(training=True). */
+int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var, float* save_invstd,
+                                   void* y, void* ws, size_t ws_bytes, void* stream);
+/* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
+int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* sums[c] = sum over the M rows of x[.][c]  (bias gradients) */
+int smirk_colsum_split16(const void* x, size_t M, int C, float* sums, void* ws, size_t ws_bytes, void* stream);
+/* nn.MaxPool2d(2, 2) backward: dx[b,2y+i,2x+j,c] = dy[b,y,x,c] at the first maximum of the window (ATen scan order), 0 elsewhere, + add (nullable:
+ * a second gradient of the same tensor, e.g. the U-Net skip connection's). */
+int smirk_maxpool2x2_backward_split16(const void* x, const void* dy, const void* add, void* dx, int B, int H, int W, int C, void* stream);
+/* nn.ReflectionPad2d(1) backward: dxp[B][H+2][W+2][C] -> dx[B][H][W][C] (+ add, nullable) */
+int smirk_reflect_pad1_backward_split16(const void* dxp, const void* add, void* dx, int B, int H, int W, int C, void* stream);
+/* [B][2H][2W][C] -> [B][H][W][(dy,dx,c)]: the ConvTranspose2d(k=2,s=2) output gradient as the operand of a 1x1 convolution / weight gradient */
+int smirk_space_to_depth2_split16(const void* in, void* out, int B, int H, int W, int C, void* stream);
+/* final Conv2d(C, Cout<=4, 1) + sigmoid backward (smirk_generator.py:47-49,76): dy, y NCHW fp32; w [Cout][C] fp32 -> dd[B][H][W][C] split16 (gradient of the
+ * conv input) and dl8[B][H][W][8] split16 (dL/dlogits, channels >= Cout zero) from which smirk_conv_wgrad_f32 / smirk_colsum_split16 give dW and db. */
+int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const float* y, const float* w, void* dd, void* dl8, int B, int H, int W, int C, int Cout,
+                                           void* stream);
+/* Weight gradient of a KHxKH (1 or 3), stride-1, pad-(KH-1)/2 (zero or reflect) convolution in exact fp32 (v_mfma_f32_32x32x2_f32):
+ * dw[Cout][(ky,kx,ci)] = sum_p dz[p][co] * x[p + (ky,kx) - pad][ci]   — the packed forward weight layout.  ConvTranspose2d(k=2,s=2): call with KH = 1,
+ * dz = the layer INPUT [M][Cin_t] and x = space_to_depth2(output gradient) [M][4*Cout_t] => dw[Cin_t][(dy,dx,co)]. */
+size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, int KH);
+int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Launch profiler (diagnostics; the one place where the library creates HIP events and synchronises — on request only).
  * Between smirk_profile_start() and smirk_profile_stop() every kernel the library launches from the calling process is bracketed
  * by a pair of hipEvents on ITS launch stream.  stop() waits for them and reports, per launch, the kernel's name as instantiated,

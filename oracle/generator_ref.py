@@ -109,3 +109,55 @@ def _forward(sd, x, res_blocks, t):
             sd["conv.bias"] = -(lg / lg.std().clamp_min(1e-6)).mean((0, 2, 3)) + sd["conv.bias"]
         t["logits"] = F.conv2d(d, sd["conv.weight"], sd["conv.bias"])
         return torch.sigmoid(t["logits"])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# TRAIN mode (BASELINE config 5 / VERDICT r1 row J1): batch-statistics BatchNorm + autograd, restated functionally.
+# Follows what nn.BatchNorm2d.train() does inside the reference's SmirkGenerator (smirk_generator.py:88-119 `_block`, :121-178 ResnetBlock):
+# normalise with the batch mean / biased variance, update running_mean / running_var with momentum 0.1 (running_var takes the UNBIASED batch
+# variance), bump num_batches_tracked.  Pinned against the real reference class by oracle/make_train_golden.py (outputs, input gradient and
+# every parameter gradient identical) and tests/golden/generator_train_golden.npz.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def train_forward(params, buffers, x, res_blocks=5, momentum=0.1, eps=1e-5):
+    """params: {name: tensor (requires_grad as the caller wishes)}, buffers: {name: tensor} (running stats; UPDATED IN PLACE like the module does).
+    x [B,6,H,W] -> sigmoid image, differentiable w.r.t. x and params."""
+    def bn(t, p):
+        return F.batch_norm(t, buffers[p + ".running_mean"], buffers[p + ".running_var"], params[p + ".weight"], params[p + ".bias"],
+                            training=True, momentum=momentum, eps=eps)
+
+    def block(t, mod, nm):
+        t = F.relu(bn(F.conv2d(t, params[f"{mod}.{nm}conv1.weight"], padding=1), f"{mod}.{nm}norm1"))
+        return F.relu(bn(F.conv2d(t, params[f"{mod}.{nm}conv2.weight"], padding=1), f"{mod}.{nm}norm2"))
+
+    e1 = block(x, "encoder1", "enc1")
+    e2 = block(F.max_pool2d(e1, 2, 2), "encoder2", "enc2")
+    e3 = block(F.max_pool2d(e2, 2, 2), "encoder3", "enc3")
+    e4 = block(F.max_pool2d(e3, 2, 2), "encoder4", "enc4")
+    b = block(F.max_pool2d(e4, 2, 2), "bottleneck", "bottleneck")
+    for k in range(res_blocks):
+        p = f"resnet_blocks.{k}.conv_block"
+        y = F.relu(bn(F.conv2d(F.pad(b, (1, 1, 1, 1), mode="reflect"), params[p + ".1.weight"]), p + ".2"))
+        b = b + bn(F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), params[p + ".5.weight"]), p + ".6")
+    d = b
+    for lvl, skip in ((4, e4), (3, e3), (2, e2), (1, e1)):
+        d = F.conv_transpose2d(d, params[f"upconv{lvl}.weight"], params[f"upconv{lvl}.bias"], stride=2)
+        d = block(torch.cat((d, skip), 1), f"decoder{lvl}", f"dec{lvl}")
+    return torch.sigmoid(F.conv2d(d, params["conv.weight"], params["conv.bias"]))
+
+
+def split_state_dict(sd):
+    """state_dict -> (params that take gradients, buffers) as fresh leaf tensors"""
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()
+              if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))}
+    buffers = {k: v.clone() for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    return params, buffers
+
+
+def train_step(sd, x, loss_weights, res_blocks=5):
+    """One forward + backward of loss = sum(y * loss_weights) in train mode.  Returns y, loss, dL/dx, {param: grad}, {buffer: updated running stat}."""
+    params, buffers = split_state_dict(sd)
+    x = x.clone().requires_grad_(True)
+    y = train_forward(params, buffers, x, res_blocks)
+    loss = (y * loss_weights).sum()
+    loss.backward()
+    return y.detach(), float(loss), x.grad, {k: v.grad for k, v in params.items()}, buffers

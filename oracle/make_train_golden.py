@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Train-mode golden of the REAL reference SmirkGenerator (src/smirk_generator.py, imported from /root/reference through oracle/sandbox.py):
+one forward in .train() mode (batch-statistics BatchNorm, running-stat update) and one backward of a fixed linear loss, B = 3, 64 x 64.
+Also asserts that the functional restatement oracle/generator_ref.py::train_step reproduces the reference class exactly.
+
+    python -m oracle.make_train_golden      ->  tests/golden/generator_train_golden.npz
+"""
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+from . import assets as A
+from . import generator_ref as G
+from . import sandbox as S
+
+GOLD = os.path.join(A.REPO, "tests", "golden")
+SEED_X, SEED_W = 51, 52
+
+
+def inputs():
+    x = A.synth_generator_input(3, seed=SEED_X)[:, :, 80:144, 72:136].contiguous()
+    w = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(SEED_W))
+    return x, w
+
+
+def main():
+    assert S.available(), "needs /root/reference"
+    d = tempfile.mkdtemp(prefix="smirk_sandbox_")
+    A.write_sandbox(d)
+    sd = G.synth_state_dict()
+    x, w = inputs()
+    with S.reference(d) as ref:
+        g = ref.SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+        g.load_state_dict(sd)
+        g.train()
+        xr = x.clone().requires_grad_(True)
+        y = g(xr)
+        loss = (y * w).sum()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in g.named_parameters()}
+        bufs = {k: v.clone() for k, v in g.named_buffers()}
+    # the functional restatement must be the same computation
+    y2, loss2, dx2, g2, b2 = G.train_step(sd, x, w)
+    assert torch.equal(y2, y.detach()), (y2 - y.detach()).abs().max()
+    assert (dx2 - xr.grad).abs().max() <= 1e-6 * xr.grad.abs().max()
+    for k in grads:
+        assert (g2[k] - grads[k]).abs().max() <= 2e-6 * max(1e-12, grads[k].abs().max()), k
+    for k in b2:
+        assert torch.equal(b2[k], bufs[k]), k
+    out = dict(seed_x=SEED_X, seed_w=SEED_W, y=y.detach().numpy(), loss=np.float64(loss.item()), dx=xr.grad.numpy())
+    for k, v in grads.items():
+        out["gnorm/" + k] = np.float64(v.double().norm().item())
+        out["ghead/" + k] = v.flatten()[:64].numpy()
+        if v.numel() <= 4096:
+            out["gfull/" + k] = v.numpy()
+    for k, v in bufs.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["buf/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, "generator_train_golden.npz"), **out)
+    print("generator_train_golden.npz", os.path.getsize(os.path.join(GOLD, "generator_train_golden.npz")) // 1024, "KiB; loss", loss.item())
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,16 @@ _SIGS = {
     "smirk_generator_forward": (_i, [C.POINTER(SmirkGeneratorWeights), _p, _i, _p, _i, _p, _i, _i, _i, C.POINTER(_p), _p, _sz, _p]),
     "smirk_backbone_workspace_bytes": (_sz, [C.POINTER(SmirkBackboneWeights), _i, _i, _i]),
     "smirk_backbone_forward": (_i, [C.POINTER(SmirkBackboneWeights), _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
+    "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "smirk_colsum_split16": (_i, [_p, _sz, _i, _p, _p, _sz, _p]),
+    "smirk_maxpool2x2_backward_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_reflect_pad1_backward_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_space_to_depth2_split16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "smirk_conv1x1_sigmoid_backward_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smirk_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_profile_start": (_i, []),
     "smirk_profile_stop": (_i, [C.POINTER(SmirkProfileRecord), _i]),
     "smirk_random_point_budget": (_i, [_p, _i, _i, C.c_float, C.c_uint64, C.c_uint64, _p]),

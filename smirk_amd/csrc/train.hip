@@ -1,0 +1,483 @@
+// Training-mode building blocks of the SmirkGenerator on MI355X (BASELINE config 5, first slice: the generator is 97 % of the step's FLOPs):
+//   * BatchNorm2d in TRAIN mode — batch statistics, normalise + affine (+ residual) (+ ReLU), running-stat update    (nn.BatchNorm2d inside
+//     smirk_generator.py:88-119 `_block` and :121-178 `ResnetBlock` after `self.train()`, base_trainer.py:108-111) — and its backward;
+//   * the backward companions of the forward kernels: weight gradient of 3x3 / 1x1 / transposed convolutions (exact fp32 MFMA), 2x2 max-pool
+//     backward, reflection-pad fold, space-to-depth of the ConvTranspose2d output gradient, final 1x1 conv + sigmoid backward.
+// Data gradients of the convolutions need no kernel of their own: dX = conv(dZ, W rotated by 180 degrees with Cin <-> Cout swapped) runs on
+// the forward implicit-GEMM / ping-pong / halo-patch kernels (the host repacks the weights once per step).
+//
+// Activations and their gradients are split16 NHWC tensors (conv_common.h): every kernel here decodes 8-channel groups to fp32, computes in
+// fp32 (reductions in fp64, two-stage and in a fixed order => bit-reproducible) and re-splits.  All kernels are HBM-bound streaming kernels
+// except the weight gradient, which is MFMA-bound at the fp32 matrix rate (157 TFLOP/s): K = B*H*W pixels is the reduction, so both operands
+// are "k-major" in memory, which is exactly the operand layout of v_mfma_f32_32x32x2_f32 (one fp32 per lane: lanes 0-31 / 32-63 hold k, k+1) —
+// no transposition is needed, and the gradient is accumulated in exact fp32.
+#include <stdio.h>
+
+#include "conv_common.h"
+
+namespace {
+
+__device__ __forceinline__ void load_group(const float* p, float* v) {
+    const half8 hi = *(const half8*)p, lo = *(const half8*)(p + 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = join1(hi[q], lo[q]);
+}
+__device__ __forceinline__ void store_group(float* p, const float* v) {
+    half8 hi, lo;
+    split8(v, hi, lo);
+    *(half8*)p = hi;
+    *(half8*)(p + 4) = lo;
+}
+
+inline unsigned blocks_for(size_t items, unsigned cap) {
+    const size_t g = (items + 255) / 256;
+    return (unsigned)(g > cap ? cap : (g ? g : 1));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// per-channel sums over the rows of a [M][C] split16 tensor: S1 = sum f(x), S2 = sum g(x); two stages, fp64, fixed order
+//   MODE 0 (statistics)      f = z,            g = z*z
+//   MODE 1 (BN backward)     f = dyh,          g = dyh * xhat      with dyh = dy * [relu ? (xhat*gamma+beta > 0) : 1], xhat = (z-mean)*invstd
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define RED_BLOCKS 512
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                     double* __restrict__ part /*[blocks][C][2]*/) {
+    __shared__ double red[256 * 2];
+    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;          // RPB rows in flight per block iteration
+    double s1[8], s2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+    float mu[8], is[8], ga[8], be[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
+    }
+    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
+        float v[8];
+        load_group(z + (r * G + g) * 8, v);
+        if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s1[q] += (double)v[q]; s2[q] += (double)v[q] * (double)v[q]; }
+        } else {
+            float d[8];
+            load_group(dy + (r * G + g) * 8, d);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float xh = (v[q] - mu[q]) * is[q];
+                const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[q];
+                s1[q] += (double)dh; s2[q] += (double)dh * (double)xh;
+            }
+        }
+    }
+    // reduce over the RPB row-lanes of each channel group (fixed order), one channel at a time through LDS
+    for (int q = 0; q < 8; ++q) {
+        red[tid * 2] = s1[q]; red[tid * 2 + 1] = s2[q];
+        __syncthreads();
+        if (rl == 0) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < RPB; ++k) { a += red[(k * G + g) * 2]; b += red[(k * G + g) * 2 + 1]; }
+            double* o = part + ((size_t)blockIdx.x * G * 8 + g * 8 + q) * 2;
+            o[0] = a; o[1] = b;
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2 of MODE 0: mean, biased variance, invstd, running-stat update (momentum; running_var takes the unbiased variance)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblocks, int C, double n, float eps, float momentum,
+                                                          float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblocks; ++k) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+    const double m = a / n;
+    double v = b / n - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m; var[c] = (float)v; invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
+}
+
+// stage 2 of MODE 1 / plain column sums: out1[c] = S1, out2[c] = S2 (as fp32)
+__global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ part, int nblocks, int C, float* __restrict__ out1, float* __restrict__ out2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblocks; ++k) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+    if (out1) out1[c] = (float)a;
+    if (out2) out2[c] = (float)b;
+}
+
+// y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t NG, int G, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, int relu, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NG; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        float v[8];
+        load_group(z + i * 8, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mean[g * 8 + q]) * invstd[g * 8 + q] * gamma[g * 8 + q] + beta[g * 8 + q];
+        if (residual) {
+            float r[8];
+            load_group(residual + i * 8, r);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += r[q];
+        }
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        store_group(y + i * 8, v);
+    }
+}
+
+// dz = gamma * invstd * (dyh - sum_dyh / n - xhat * sum_dyh_xhat / n)
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t NG, int G, float inv_n,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
+                                                                float* __restrict__ dz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NG; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        float v[8], d[8];
+        load_group(z + i * 8, v);
+        load_group(dy + i * 8, d);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = g * 8 + q;
+            const float xh = (v[q] - mean[c]) * invstd[c];
+            const float dh = (relu && !(xh * gamma[c] + beta[c] > 0.f)) ? 0.f : d[q];
+            v[q] = gamma[c] * invstd[c] * (dh - sum_dy[c] * inv_n - xh * sum_dy_xhat[c] * inv_n);
+        }
+        store_group(dz + i * 8, v);
+    }
+}
+
+// 2x2/2 max-pool backward: the gradient goes to the first maximum of the window in scan order (ATen's max_pool2d picks `val > max`), plus an
+// optional second gradient of the same tensor (the U-Net skip connection) added in.  x, dx [B][H][W][G*8]; dy [B][H/2][W/2][G*8]
+__global__ __launch_bounds__(256) void maxpool_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ add,
+                                                               float* __restrict__ dx, int B, int H, int W, int G) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const size_t p00 = ((((size_t)b * H + 2 * oy) * W + 2 * ox) * G + g) * 8, sx = (size_t)G * 8, sy = (size_t)W * G * 8;
+        float v[4][8], gy[8], o[4][8];
+        load_group(x + p00, v[0]); load_group(x + p00 + sx, v[1]); load_group(x + p00 + sy, v[2]); load_group(x + p00 + sy + sx, v[3]);
+        load_group(dy + i * 8, gy);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int best = 0;
+            float m = v[0][q];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][q] > m) { m = v[k][q]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][q] = (k == best) ? gy[q] : 0.f;
+        }
+        const size_t off[4] = {p00, p00 + sx, p00 + sy, p00 + sy + sx};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (add) {
+                float a[8];
+                load_group(add + off[k], a);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[k][q] += a[q];
+            }
+            store_group(dx + off[k], o[k]);
+        }
+    }
+}
+
+// backward of ReflectionPad2d(1): dxp [B][H+2][W+2][G*8] -> dx [B][H][W][G*8] (+ optional add); padded index 0 mirrors row 1, H+1 mirrors row H-2
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dxp, const float* __restrict__ add, float* __restrict__ dx, int B, int H,
+                                                           int W, int G) {
+    const size_t total = (size_t)B * H * W * G;
+    const int Hp = H + 2, Wp = W + 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        int ys[2] = {y + 1, -1}, xs[2] = {x + 1, -1};
+        if (y == 1) ys[1] = 0;
+        if (y == H - 2) ys[1] = (ys[1] < 0) ? Hp - 1 : ys[1];            // H == 3: both borders mirror into row 1 (handled below)
+        if (x == 1) xs[1] = 0;
+        if (x == W - 2) xs[1] = (xs[1] < 0) ? Wp - 1 : xs[1];
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        if (add) load_group(add + i * 8, acc);
+        // general form (also right for H or W == 3, where a row collects both borders): walk all padded rows / cols that reflect onto (y, x)
+        for (int yp = 0; yp < Hp; ++yp) {
+            int ry = yp - 1; ry = ry < 0 ? -ry : ry; ry = ry >= H ? 2 * H - 2 - ry : ry;
+            if (ry != y) continue;
+            for (int xp = 0; xp < Wp; ++xp) {
+                int rx = xp - 1; rx = rx < 0 ? -rx : rx; rx = rx >= W ? 2 * W - 2 - rx : rx;
+                if (rx != x) continue;
+                float v[8];
+                load_group(dxp + ((((size_t)b * Hp + yp) * Wp + xp) * G + g) * 8, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += v[q];
+            }
+        }
+        (void)ys; (void)xs;
+        store_group(dx + i * 8, acc);
+    }
+}
+
+// ConvTranspose2d(k=2, s=2) output gradient [B][2H][2W][Co] -> [B][H][W][(dy,dx,co)] : the layout in which its input gradient is a 1x1 convolution
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int G) {
+    const size_t total = (size_t)B * H * W * 4 * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int q = (int)(t % 4); t /= 4;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const float* src = in + ((((size_t)b * 2 * H + 2 * y + (q >> 1)) * 2 * W + 2 * x + (q & 1)) * G + g) * 8;
+        *(f32x4*)(out + i * 8) = *(const f32x4*)src;
+        *(f32x4*)(out + i * 8 + 4) = *(const f32x4*)(src + 4);
+    }
+}
+
+// final 1x1 conv + sigmoid backward (smirk_generator.py:47-49,76): dl[o] = dy * y * (1 - y) -> dl8 (split16, [pixels][8], channels >= Cout zero: the
+// "output gradient" operand from which the generic weight-gradient / column-sum kernels produce dW and db deterministically);
+// dd[c] = sum_o dl[o] w[o][c] (split16 out)
+__global__ __launch_bounds__(256) void final_backward_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ w,
+                                                             float* __restrict__ dd, float* __restrict__ dl8, int B, int HW, int C, int Cout) {
+    const size_t total = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i % HW;
+        float dl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < Cout) {
+                const float yy = y[(b * Cout + o) * HW + p];
+                dl[o] = dy[(b * Cout + o) * HW + p] * yy * (1.0f - yy);
+            }
+        store_group(dl8 + i * 8, dl);
+        for (int g = 0; g < C / 8; ++g) {
+            float o8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < Cout) s = fmaf(dl[o], w[o * C + g * 8 + q], s);
+                o8[q] = s;
+            }
+            store_group(dd + (i * (C / 8) + g) * 8, o8);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[co][tap][ci] = sum over pixels p of dZ[p][co] * X[p shifted by tap][ci]     (exact fp32 on v_mfma_f32_32x32x2_f32)
+//   workgroup = 128 (co) x 128 (ci) tile of one tap, one K split of the pixel range; 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA blocks;
+//   16 pixels per chunk staged as fp32 [k][128 + 4] in LDS (decoded from split16), fragment = one ds_read_b32 per lane and MFMA.
+// part[split][Cout][KH*KW][Cin] fp32 partials are summed in split order by wgrad_reduce_kernel  (bit-reproducible).
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define WG_KC 16
+#define WG_LD 132
+struct WgradArgs {
+    const float *dz, *x;         // split16 [B][H][W][Cout], [B][H][W][Cin]
+    float* part;
+    int B, H, W, Cout, Cin, KH, pad, reflect;
+    int chunks_per_split;        // 16-pixel chunks per K split
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[WG_KC * WG_LD], Bs[WG_KC * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ntaps = a.KH * a.KH;
+    const int cot = blockIdx.x, cit = blockIdx.y % ((a.Cin + 127) / 128), tap = blockIdx.y / ((a.Cin + 127) / 128), split = blockIdx.z;
+    const int ky = tap / a.KH, kx = tap % a.KH;
+    const int co0 = cot * 128, ci0 = cit * 128;
+    const long long npix = (long long)a.B * a.H * a.W;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging: thread -> (pixel k = tid / 16, 8-channel group = tid % 16) of the 16 x 128 tile
+    const int sk = tid >> 4, sg = tid & 15;
+    const int Gout = a.Cout / 8, Gin = a.Cin / 8;
+    for (int c = 0; c < a.chunks_per_split; ++c) {
+        const long long p = ((long long)split * a.chunks_per_split + c) * WG_KC + sk;
+        float va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { va[q] = 0.f; vb[q] = 0.f; }
+        if (p < npix) {
+            const int gco = co0 / 8 + sg;
+            if (gco < Gout) load_group(a.dz + ((size_t)p * Gout + gco) * 8, va);
+            const int gci = ci0 / 8 + sg;
+            if (gci < Gin) {
+                const int x0 = (int)(p % a.W), y0 = (int)((p / a.W) % a.H);
+                const long long b = p / ((long long)a.W * a.H);
+                int iy = y0 + ky - a.pad, ix = x0 + kx - a.pad;
+                bool ok = true;
+                if (a.reflect) { iy = reflect_idx(iy, a.H); ix = reflect_idx(ix, a.W); }
+                else ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                if (ok) load_group(a.x + ((((size_t)b * a.H + iy) * a.W + ix) * Gin + gci) * 8, vb);
+            }
+        }
+        __syncthreads();                                           // previous chunk's fragment reads are done
+        *(f32x4*)(As + sk * WG_LD + sg * 8) = *(f32x4*)va; *(f32x4*)(As + sk * WG_LD + sg * 8 + 4) = *(f32x4*)(va + 4);
+        *(f32x4*)(Bs + sk * WG_LD + sg * 8) = *(f32x4*)vb; *(f32x4*)(Bs + sk * WG_LD + sg * 8 + 4) = *(f32x4*)(vb + 4);
+        __syncthreads();
+        const int kk = lane >> 5, mm = lane & 31;
+#pragma unroll
+        for (int k2 = 0; k2 < WG_KC; k2 += 2) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = As[(k2 + kk) * WG_LD + (wm * 2 + i) * 32 + mm];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[(k2 + kk) * WG_LD + (wn * 2 + j) * 32 + mm];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = a.part + (size_t)split * a.Cout * ntaps * a.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + (wn * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * 2 + i) * 32 + mfma32_row(r, lane);
+                if (co < a.Cout && ci < a.Cin) out[((size_t)co * ntaps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ dw) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" size_t smirk_train_reduce_workspace_bytes(int C) { return (size_t)RED_BLOCKS * (size_t)C * 2 * sizeof(double); }
+
+extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
+                                              float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var,
+                                              float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !ws || M == 0 || C <= 0 || C % 8 || 256 % (C / 8)) return SMIRK_ERR_BAD_ARG;
+    if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 8, RPB = 256 / G;
+    const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
+    smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
+    SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
+                 (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+    SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
+                 save_invstd, running_mean, running_var);
+    smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
+    SMIRK_LAUNCH(bn_apply_kernel, dim3(blocks_for(M * G, 16384)), dim3(256), 0, st, (const float*)z, M * (size_t)G, G, (const float*)save_mean,
+                 (const float*)save_invstd, gamma, beta, (const float*)residual, relu, (float*)y);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
+                                               const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                               void* stream) {
+    if (!z || !dy || !gamma || !beta || !save_mean || !save_invstd || !dz || !dgamma || !dbeta || !ws || M == 0 || C <= 0 || C % 8 || 256 % (C / 8))
+        return SMIRK_ERR_BAD_ARG;
+    if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 8, RPB = 256 / G;
+    const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
+    SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
+    SMIRK_LAUNCH(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
+    SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(blocks_for(M * G, 16384)), dim3(256), 0, st, (const float*)z, (const float*)dy, M * (size_t)G, G,
+                 (float)(1.0 / (double)M), save_mean, save_invstd, gamma, beta, (const float*)dbeta, (const float*)dgamma, relu, (float*)dz);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_colsum_split16(const void* x, size_t M, int C, float* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !sums || !ws || M == 0 || C <= 0 || C % 8 || 256 % (C / 8)) return SMIRK_ERR_BAD_ARG;
+    if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 8, RPB = 256 / G;
+    const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
+    SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)x, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
+                 (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+    SMIRK_LAUNCH(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, sums, (float*)nullptr);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_maxpool2x2_backward_split16(const void* x, const void* dy, const void* add, void* dx, int B, int H, int W, int C, void* stream) {
+    if (!x || !dy || !dx || B <= 0 || H % 2 || W % 2 || C % 8 || C <= 0) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(maxpool_backward_kernel, dim3(blocks_for((size_t)B * (H / 2) * (W / 2) * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream,
+                 (const float*)x, (const float*)dy, (const float*)add, (float*)dx, B, H, W, C / 8);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_reflect_pad1_backward_split16(const void* dxp, const void* add, void* dx, int B, int H, int W, int C, void* stream) {
+    if (!dxp || !dx || B <= 0 || H < 2 || W < 2 || C % 8 || C <= 0) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(reflect_fold_kernel, dim3(blocks_for((size_t)B * H * W * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)dxp,
+                 (const float*)add, (float*)dx, B, H, W, C / 8);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_space_to_depth2_split16(const void* in, void* out, int B, int H, int W, int C, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C % 8 || C <= 0) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(space_to_depth_kernel, dim3(blocks_for((size_t)B * H * W * 4 * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)in,
+                 (float*)out, B, H, W, C / 8);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const float* y, const float* w, void* dd, void* dl8, int B, int H, int W, int C,
+                                                      int Cout, void* stream) {
+    if (!dy || !y || !w || !dd || !dl8 || B <= 0 || C % 8 || C <= 0 || Cout <= 0 || Cout > 4) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(final_backward_kernel, dim3(blocks_for((size_t)B * H * W, 16384)), dim3(256), 0, (hipStream_t)stream, dy, y, w, (float*)dd, (float*)dl8, B,
+                 H * W, C, Cout);
+    return smirk_launch_status();
+}
+
+extern "C" size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, int KH) {
+    const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
+    long long nsplit = chunks < 64 ? chunks : 64;
+    return (size_t)nsplit * Cout * KH * KH * Cin * 4;
+}
+/* dW[Cout][(ky,kx,ci)] (fp32, the packed forward layout) = sum over pixels of dz[p][co] * x[p + tap][ci];  KH in {1, 3}, pad = (KH-1)/2 */
+extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || Cout % 8 || Cin % 8 || Cout <= 0 || Cin <= 0 || (KH != 1 && KH != 3)) return SMIRK_ERR_BAD_ARG;
+    if (ws_bytes < smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH)) return SMIRK_ERR_WORKSPACE;
+    const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
+    const int nsplit = (int)(chunks < 64 ? chunks : 64);
+    WgradArgs a;
+    a.dz = (const float*)dz; a.x = (const float*)x; a.part = (float*)ws;
+    a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.pad = (KH - 1) / 2; a.reflect = reflect;
+    a.chunks_per_split = (int)((chunks + nsplit - 1) / nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((Cout + 127) / 128, ((Cin + 127) / 128) * KH * KH, nsplit);
+    smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * Cin * KH * KH, 0.0);
+    SMIRK_LAUNCH(wgrad_kernel, grid, dim3(256), 0, st, a);
+    const size_t n = (size_t)Cout * KH * KH * Cin;
+    SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, st, (const float*)ws, nsplit, n, dw);
+    return smirk_launch_status();
+}

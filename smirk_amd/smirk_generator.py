@@ -11,7 +11,7 @@ Two arithmetic modes (`SmirkGenerator.precision`, default from $SMIRK_AMD_GENERA
   "f16x3"  split-fp16: activations/weights carried as fp16 (hi, lo) pairs, 3 fp16 MFMAs per product with fp32 accumulation —
            fp32-class accuracy (same error vs fp64 as an fp32 GEMM) at the 16-bit matrix rate; CDNA4 has no TF32.
   "f32"    exact fp32 FMA chain on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak).
-Eval mode only this round (the cycle-path training step is BASELINE config 5 / SURVEY.md §7 step 7).
+Train mode (`.train()`): batch-statistics BatchNorm + a full backward pass, see smirk_amd/generator_train.py (BASELINE config 5, generator slice).
 """
 import os
 from collections import OrderedDict
@@ -164,7 +164,13 @@ class SmirkGenerator(nn.Module):
         """One call of smirk_generator_forward: cat(a, b) NCHW -> sigmoid image.  Every layer is enqueued from C on the current stream; the
         activations live in a per-stream workspace owned by this module."""
         if self.training:
-            raise NotImplementedError("smirk_amd.SmirkGenerator implements the eval-mode forward only (call .eval())")
+            # train mode (smirk_trainer.py:349-355 calls self.train() before every step): batch-statistics BatchNorm with running-stat updates and a
+            # real backward pass — one autograd.Function over the whole network (smirk_amd/generator_train.py, csrc/train.hip)
+            if self.precision != "f16x3":
+                raise L.SmirkHipError("train mode runs in the split-fp16 ('f16x3') arithmetic mode")
+            from .generator_train import GeneratorTrainFunction
+            x = a if b is None else torch.cat([a, b], 1)
+            return GeneratorTrainFunction.apply(self, x, *self.parameters())
         srcs = [a] + ([] if b is None else [b])
         a = L.as_f32c(a.detach())
         b = None if b is None else L.as_f32c(b.detach())
