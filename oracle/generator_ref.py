@@ -145,19 +145,19 @@ def train_forward(params, buffers, x, res_blocks=5, momentum=0.1, eps=1e-5):
     return torch.sigmoid(F.conv2d(d, params["conv.weight"], params["conv.bias"]))
 
 
-def split_state_dict(sd):
-    """state_dict -> (params that take gradients, buffers) as fresh leaf tensors"""
-    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()
+def split_state_dict(sd, dtype=torch.float32):
+    """state_dict -> (params that take gradients, buffers) as fresh leaf tensors (dtype=torch.float64 gives the high-precision arbiter)"""
+    params = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd.items()
               if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))}
-    buffers = {k: v.clone() for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    buffers = {k: v.clone().to(dtype) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
     return params, buffers
 
 
-def train_step(sd, x, loss_weights, res_blocks=5):
+def train_step(sd, x, loss_weights, res_blocks=5, dtype=torch.float32):
     """One forward + backward of loss = sum(y * loss_weights) in train mode.  Returns y, loss, dL/dx, {param: grad}, {buffer: updated running stat}."""
-    params, buffers = split_state_dict(sd)
-    x = x.clone().requires_grad_(True)
+    params, buffers = split_state_dict(sd, dtype)
+    x = x.clone().to(dtype).requires_grad_(True)
     y = train_forward(params, buffers, x, res_blocks)
-    loss = (y * loss_weights).sum()
+    loss = (y * loss_weights.to(dtype)).sum()
     loss.backward()
-    return y.detach(), float(loss), x.grad, {k: v.grad for k, v in params.items()}, buffers
+    return y.detach(), float(loss.detach()), x.grad, {k: v.grad for k, v in params.items()}, buffers

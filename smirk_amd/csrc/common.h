@@ -8,6 +8,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// fp32 -> split-fp16 pair (value = hi + lo * 2^-11).  The empty asm pins v as a ROUNDED fp32 register value.  Without it the compiler folds a
+// preceding multiply into the conversion (v_fma_mixlo_f16: one rounding of the exact product) while the residual is still taken from the fp32-rounded
+// product; at an exact tie the two disagree about which fp16 neighbour `hi` is and the pair lands a whole fp16 ulp away from v (measured: 1 element in
+// ~16k off by 6e-4 relative in the BatchNorm backward, tests/test_train_ops_gpu.py).
+__device__ __forceinline__ void smirk_split1(float v, _Float16& hi, _Float16& lo) {
+    asm("" : "+v"(v));
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * 2048.0f);
+}
+
 #define SMIRK_WAVE 64
 
 static inline size_t smirk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -37,9 +37,9 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const _Float16 h = (_Float16)v[q];
-        hi[q] = h;
-        lo[q] = (_Float16)((v[q] - (float)h) * 2048.0f);
+        _Float16 h, l;
+        smirk_split1(v[q], h, l);
+        hi[q] = h; lo[q] = l;
     }
 }
 __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }

@@ -80,9 +80,9 @@ __device__ __forceinline__ int lds_piece_p(int row, int piece) { return row * 32
 __device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const _Float16 h = (_Float16)v[q];
-        hi[q] = h;
-        lo[q] = (_Float16)((v[q] - (float)h) * 2048.0f);
+        _Float16 h, l;
+        smirk_split1(v[q], h, l);
+        hi[q] = h; lo[q] = l;
     }
 }
 

@@ -200,9 +200,9 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = fmaxf(acc[k] * s2[k] + b2[k], 0.f);
-                    const _Float16 h = (_Float16)v;
-                    hi[k] = h;
-                    lo[k] = (_Float16)((v - (float)h) * 2048.0f);
+                    _Float16 h, l;
+                    smirk_split1(v, h, l);
+                    hi[k] = h; lo[k] = l;
                 }
                 char* d = Ds + p * DSB + (c4 >> 1) * 32 + (c4 & 1) * 8;
                 *(half4*)d = hi;
@@ -274,9 +274,9 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
             half8 hi, lo;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const _Float16 h = (_Float16)v[k];
-                hi[k] = h;
-                lo[k] = (_Float16)((v[k] - (float)h) * 2048.0f);
+                _Float16 h, l;
+                smirk_split1(v[k], h, l);
+                hi[k] = h; lo[k] = l;
             }
             char* o = ob + ((size_t)oy * a.Wo + ox) * a.Cout * 4 + g8 * 32;
             *(half8*)o = hi;

@@ -70,12 +70,16 @@ def test_generator_odd_batch_and_small_image(gen):
     assert (yg - yr).abs().max().item() < OUT_TOL
 
 
-def test_generator_train_mode_raises(gen):
+def test_generator_train_mode_rejects_bad_shapes_loudly(gen):
+    """train mode is the HIP training path (tests/test_generator_train_gpu.py); what it cannot run must raise, not fall back"""
+    from smirk_amd import SmirkHipError
     m, _ = gen
     m.train()
     try:
-        with pytest.raises(NotImplementedError):
-            m(torch.zeros(1, 6, 32, 32).cuda())
+        with pytest.raises(SmirkHipError):
+            m(torch.zeros(1, 6, 40, 40).cuda())                    # H, W not multiples of 16
+        with pytest.raises(SmirkHipError):
+            m(torch.zeros(1, 5, 32, 32).cuda())                    # wrong channel count
     finally:
         m.eval()
 
