@@ -389,6 +389,25 @@ size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, 
 int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* ---- train-mode SmirkEncoder backbones (csrc/train_encoder.hip): what `self.train()` + autograd does to the timm
+ * tf_mobilenetv3_{small,large}_minimal_100 feature extractors of smirk_encoder.py:7-12 (pointwise convolutions and BatchNorm reuse the entries above).
+ * Stem Conv2d(3, Cout, 3, stride 2, TF 'SAME') WITHOUT BatchNorm / ReLU (train mode normalises with batch statistics afterwards): img NCHW fp32,
+ * w [Cout][(ky,kx,c)] fp32 -> out split16 [B][ceil(H/2)][ceil(W/2)][Cout] */
+int smirk_stem_conv_s2_raw_split16(const float* img, const float* w, void* out, int B, int H, int W, int Cout, void* stream);
+/* its weight gradient dw[Cout][(ky,kx,c)] and image gradient dimg NCHW fp32 (the gradient the cycle path returns to the generator, smirk_trainer.py:293-297) */
+size_t smirk_stem_conv_s2_wgrad_workspace_bytes(int Cout);
+int smirk_stem_conv_s2_wgrad_split16(const float* img, const void* dz, float* dw, int B, int H, int W, int Cout, void* ws, size_t ws_bytes, void* stream);
+int smirk_stem_conv_s2_dgrad_split16(const void* dz, const float* w, float* dimg, int B, int H, int W, int Cout, void* stream);
+/* depthwise 3x3 (stride 1 pad 1, or stride 2 TF 'SAME'; w [9][C] fp32 as smirk_dwconv3x3_split16 takes it): data gradient dx[B][H][W][C] (+ add, nullable:
+ * the skip connection's gradient) from dz[B][ceil(H/s)][ceil(W/s)][C], and weight gradient dw[9][C] */
+int smirk_dwconv3x3_dgrad_split16(const void* dz, const float* w, const void* add, void* dx, int B, int H, int W, int C, int stride, void* stream);
+size_t smirk_dwconv3x3_wgrad_workspace_bytes(int C);
+int smirk_dwconv3x3_wgrad_split16(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
+/* F.adaptive_avg_pool2d(features, 1) + nn.Linear backward (smirk_encoder.py:18-22): dout [B][N], w [N][C], pooled [B][C] (the forward's workspace) ->
+ * dw [N][C], db [N] (both or neither), dfeat split16 [B][HW][C] (nullable) */
+int smirk_gap_linear_backward_split16(const float* dout, const float* w, const float* pooled, float* dw, float* db, void* dfeat, int B, int HW, int C, int N,
+                                      void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Launch profiler (diagnostics; the one place where the library creates HIP events and synchronises — on request only).
  * Between smirk_profile_start() and smirk_profile_stop() every kernel the library launches from the calling process is bracketed

@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = C.c_void_p
 _i = C.c_int
@@ -137,6 +137,14 @@ _SIGS = {
     "smirk_conv1x1_sigmoid_backward_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_stem_conv_s2_raw_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_stem_conv_s2_wgrad_workspace_bytes": (_sz, [_i]),
+    "smirk_stem_conv_s2_wgrad_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_stem_conv_s2_dgrad_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "smirk_dwconv3x3_dgrad_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smirk_dwconv3x3_wgrad_workspace_bytes": (_sz, [_i]),
+    "smirk_dwconv3x3_wgrad_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_gap_linear_backward_split16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_profile_start": (_i, []),
     "smirk_profile_stop": (_i, [C.POINTER(SmirkProfileRecord), _i]),
     "smirk_random_point_budget": (_i, [_p, _i, _i, C.c_float, C.c_uint64, C.c_uint64, _p]),

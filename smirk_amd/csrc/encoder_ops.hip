@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         float* __restrict__ out, int B, int H, int W, int Cout, int split) {
     extern __shared__ float sw[];   // [27][Cout] transposed weights, then scale[Cout], shift[Cout]
     for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) { const int k = i / Cout, co = i % Cout; sw[i] = w[co * 27 + k]; }
-    for (int i = threadIdx.x; i < Cout; i += blockDim.x) { sw[27 * Cout + i] = scale[i]; sw[28 * Cout + i] = shift[i]; }
+    const bool raw = (split & 2) != 0;                 // training: the bare convolution (BatchNorm takes batch statistics afterwards)
+    split &= 1;
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) { sw[27 * Cout + i] = raw ? 1.f : scale[i]; sw[28 * Cout + i] = raw ? 0.f : shift[i]; }
     __syncthreads();
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pt = same_pad_lead(H, 2), pl = same_pad_lead(W, 2);
@@ -55,8 +57,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             for (int k = 0; k < 27; ++k)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc[q] = fmaf(x[k], sw[k * Cout + co + q], acc[q]);
+            if (!raw) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = fmaxf(acc[q] * sw[27 * Cout + co + q] + sw[28 * Cout + co + q], 0.f);
+                for (int q = 0; q < 8; ++q) acc[q] = fmaxf(acc[q] * sw[27 * Cout + co + q] + sw[28 * Cout + co + q], 0.f);
+            }
             if (split) {
                 half8 hi, lo;
                 enc_split8(acc, hi, lo);
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 
 static int stem_launch(const float* img, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
                        int Cout, void* stream, int split) {
-    if (!img || !w || !scale || !shift || !out || B <= 0 || Cout % 8 || Cout <= 0 || Cout > 64) return SMIRK_ERR_BAD_ARG;
+    if (!img || !w || (!(split & 2) && (!scale || !shift)) || !out || B <= 0 || Cout % 8 || Cout <= 0 || Cout > 64) return SMIRK_ERR_BAD_ARG;
     const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
     const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     smirk_prof_next(nullptr, 54.0 * B * ((H + 1) / 2) * ((W + 1) / 2) * Cout, 4.0 * ((double)B * 3 * H * W + (double)B * ((H + 1) / 2) * ((W + 1) / 2) * Cout));
@@ -87,6 +91,9 @@ extern "C" int smirk_stem_conv_s2(const float* img, const float* w, const float*
 extern "C" int smirk_stem_conv_s2_split16(const float* img, const float* w, const float* scale, const float* shift, void* out,
                                           int B, int H, int W, int Cout, void* stream) {
     return stem_launch(img, w, scale, shift, (float*)out, B, H, W, Cout, stream, 1);
+}
+extern "C" int smirk_stem_conv_s2_raw_split16(const float* img, const float* w, void* out, int B, int H, int W, int Cout, void* stream) {
+    return stem_launch(img, w, nullptr, nullptr, (float*)out, B, H, W, Cout, stream, 3);
 }
 
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const f32x4* __restrict__ in, const f32x4* __restrict__ w,

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                      double* __restrict__ part /*[blocks][C][2]*/) {
     __shared__ double red[256 * 2];
-    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;          // RPB rows in flight per block iteration
+    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;          // RPB rows in flight per block iteration; when G does not
+    const bool active = rl < RPB;                                                   // divide 256 the last 256 - RPB*G threads only attend the barriers
     double s1[8], s2[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
 #pragma unroll
         for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
     }
-    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
+    for (size_t r = (size_t)blockIdx.x * RPB + rl; active && r < M; r += (size_t)gridDim.x * RPB) {
         float v[8];
         load_group(z + (r * G + g) * 8, v);
         if (MODE == 0) {
@@ -384,7 +385,7 @@ extern "C" size_t smirk_train_reduce_workspace_bytes(int C) { return (size_t)RED
 extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
                                               float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var,
                                               float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream) {
-    if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !ws || M == 0 || C <= 0 || C % 8 || 256 % (C / 8)) return SMIRK_ERR_BAD_ARG;
+    if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !ws || M == 0 || C <= 0 || C % 8 || C / 8 > 256) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
@@ -403,7 +404,7 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
 extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                                                const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                                void* stream) {
-    if (!z || !dy || !gamma || !beta || !save_mean || !save_invstd || !dz || !dgamma || !dbeta || !ws || M == 0 || C <= 0 || C % 8 || 256 % (C / 8))
+    if (!z || !dy || !gamma || !beta || !save_mean || !save_invstd || !dz || !dgamma || !dbeta || !ws || M == 0 || C <= 0 || C % 8 || C / 8 > 256)
         return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -417,7 +418,7 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
 }
 
 extern "C" int smirk_colsum_split16(const void* x, size_t M, int C, float* sums, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !sums || !ws || M == 0 || C <= 0 || C % 8 || 256 % (C / 8)) return SMIRK_ERR_BAD_ARG;
+    if (!x || !sums || !ws || M == 0 || C <= 0 || C % 8 || C / 8 > 256) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;

@@ -177,7 +177,12 @@ class MobileNetV3Features(nn.Module):
         """ONE call of smirk_backbone_forward (csrc/network.hip): stem -> blocks -> (global average pool -> Linear `head` (+ clamps)).
         Returns (head output [B, n_out] or None, last feature map NHWC or None)."""
         if self.training:
-            raise NotImplementedError("smirk_amd encoders implement the eval-mode forward only (call .eval())")
+            # batch-statistics BatchNorm + autograd (smirk_trainer.py:349-355 calls self.train() before every step): csrc/train*.hip
+            if head is None or want_features:
+                raise L.SmirkHipError("train-mode backbone runs together with its Linear head (the encoders' own forward); use .eval() for bare features")
+            from .encoder_train import BackboneTrainFunction
+            out = BackboneTrainFunction.apply(self, head, clamp_n_exp, img, *(list(self.parameters()) + list(head.parameters())))
+            return out, None
         src = img
         img = L.as_f32c(img.detach())
         if not img.is_cuda:
@@ -251,7 +256,7 @@ class MobileNetV3Features(nn.Module):
             return self.run(img, want_features=True)[1]
         # per-layer schedule driven from Python: the debugging twin of smirk_backbone_forward (same kernels, same order), kept for `_taps`
         if self.training:
-            raise NotImplementedError("smirk_amd encoders implement the eval-mode forward only (call .eval())")
+            raise L.SmirkHipError("the per-layer debugging schedule is eval-mode only; train mode runs through the encoders' forward (encoder_train.py)")
         lib, st, P = L.lib(), L.stream_ptr(), self._pack()
         img = L.as_f32c(img)
         B, _, H, W = img.shape
@@ -363,7 +368,7 @@ class SmirkEncoder(nn.Module):
         outputs = {}
         if not img.is_cuda:
             raise L.SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
-        if os.environ.get("SMIRK_ENCODER_SERIAL"):              # profiling aid: one stream, reference order
+        if os.environ.get("SMIRK_ENCODER_SERIAL") or self.training:   # profiling aid / training (one autograd graph, one stream): reference order
             for enc in (self.pose_encoder, self.shape_encoder, self.expression_encoder):
                 outputs.update(enc(img))
             return outputs

@@ -201,3 +201,142 @@ def test_head_conv1x1_sigmoid_backward(B, H, W, C):
     assert (y.cpu().double() - yr.detach()).abs().max().item() < 2e-6
     assert _rel(_val(dd), x.grad) < 2e-5          # y (fp32, from the forward) enters as y*(1-y): its 1e-7 error is relative to 0.25, not to dd
     assert _rel(gw.cpu().reshape(3, C, 1, 1), w64.grad) < 2e-5 and _rel(gb.cpu(), b64.grad) < 2e-5
+
+
+# ---- encoder-specific training kernels (csrc/train_encoder.hip) -----------------------------------------------------------------------
+def _enc_ops():
+    from smirk_amd import encoder_train as E
+    return E, E._EncOps(torch.device("cuda"))
+
+
+def _same_pad(x, k, s):
+    """timm Conv2dSame padding (layers/padding.py): total = max((ceil(n/s)-1)*s + k - n, 0), leading = total // 2"""
+    import math
+    ih, iw = x.shape[-2:]
+    ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+    pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+    return F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+
+
+@pytest.mark.parametrize("C", [24, 40, 72, 200, 960])
+def test_batchnorm_train_channel_counts_that_do_not_divide_256(C):
+    """the MobileNet widths: 8-channel groups that do not tile a 256-thread block evenly"""
+    T, ops = _ops()
+    g = _gen(C)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.3 + 1.5)
+    ga, be = bn.weight.detach().cpu().double(), bn.bias.detach().cpu().double()
+    zs, z64 = _act(torch.randn(3, 5, 7, C, generator=g) + 0.3)
+    dys, dy64 = _act(torch.randn(3, 5, 7, C, generator=g))
+    y, mean, inv = ops.bn_forward(zs, bn, False)
+    zr = z64.clone().requires_grad_(True)
+    gr, br = ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    yr = F.batch_norm(zr, None, None, gr, br, True, 0.1, 1e-3)
+    yr.backward(dy64)
+    dz, dg, db = ops.bn_backward(zs, dys, bn, mean, inv, False)
+    e = dict(y=_rel(_val(y), yr.detach()), dz=_rel(_val(dz), zr.grad), dg=_rel(dg.cpu(), gr.grad), db=_rel(db.cpu(), br.grad))
+    assert all(v < TOL for v in e.values()), e
+
+
+@pytest.mark.parametrize("B,H,W,C,stride,add", [(2, 8, 8, 16, 1, True), (2, 9, 7, 24, 2, False), (1, 14, 14, 72, 2, False), (3, 7, 7, 960, 1, False),
+                                                 (2, 12, 12, 64, 2, False), (2, 6, 6, 40, 1, True)])
+def test_depthwise_conv_backward(B, H, W, C, stride, add):
+    """depthwise 3x3, stride 1 (pad 1) and stride 2 (TF 'SAME': asymmetric padding on even sizes) — forward, data gradient (+ skip gradient), weight gradient"""
+    E, ops = _enc_ops()
+    from smirk_amd import _lib as L
+    g = _gen(H * C + stride)
+    wt = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    xs, x64 = _act(torch.randn(B, H, W, C, generator=g))
+    w9c = wt.reshape(C, 9).t().contiguous().cuda()
+    z = ops.depthwise(xs, w9c, stride)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    ds, d64 = _act(torch.randn(B, Ho, Wo, C, generator=g))
+    as_, a64 = _act(torch.randn(B, H, W, C, generator=g)) if add else (None, None)
+    x = x64.clone().requires_grad_(True)
+    w64 = wt.double().requires_grad_(True)
+    zr = F.conv2d(_same_pad(x, 3, stride), w64, stride=stride, groups=C) if stride == 2 else F.conv2d(x, w64, padding=1, groups=C)
+    assert _rel(_val(z), zr.detach()) < TOL
+    zr.backward(d64)
+    dx = ops.depthwise_dgrad(ds, w9c, as_, B, H, W, C, stride)
+    assert _rel(_val(dx), x.grad + (a64 if add else 0)) < TOL
+    dw = ops.depthwise_wgrad(ds, xs, stride)
+    assert _rel(dw.cpu(), w64.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 45, 37), (3, 64, 48)])
+def test_stem_conv_backward(B, H, W):
+    """Conv2d(3, 16, 3, stride 2, TF 'SAME') from an NCHW fp32 image: bare forward, weight gradient, image gradient"""
+    E, ops = _enc_ops()
+    from smirk_amd import _lib as L
+    g = _gen(H + W)
+    wt = torch.randn(16, 3, 3, 3, generator=g) * 0.2
+    img = torch.rand(B, 3, H, W, generator=g)
+    wp = wt.permute(0, 2, 3, 1).reshape(16, 27).contiguous().cuda()
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    z = torch.empty(B, Ho, Wo, 16, device="cuda")
+    imgc = img.cuda()
+    L.check(ops.lib.smirk_stem_conv_s2_raw_split16(L.ptr(imgc), L.ptr(wp), L.ptr(z), B, H, W, 16, ops.st))
+    x = img.double().requires_grad_(True)
+    w64 = wt.double().requires_grad_(True)
+    zr = F.conv2d(_same_pad(x, 3, 2), w64, stride=2)
+    assert _rel(_val(z), zr.detach()) < TOL
+    ds, d64 = _act(torch.randn(B, Ho, Wo, 16, generator=g))
+    zr.backward(d64)
+    nws = ops.lib.smirk_stem_conv_s2_wgrad_workspace_bytes(16)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    dw = torch.empty(16, 27, device="cuda")
+    L.check(ops.lib.smirk_stem_conv_s2_wgrad_split16(L.ptr(imgc), L.ptr(ds), L.ptr(dw), B, H, W, 16, L.ptr(ws, torch.uint8), nws, ops.st))
+    assert _rel(dw.reshape(16, 3, 3, 3).permute(0, 3, 1, 2).cpu(), w64.grad) < TOL
+    dimg = torch.empty(B, 3, H, W, device="cuda")
+    L.check(ops.lib.smirk_stem_conv_s2_dgrad_split16(L.ptr(ds), L.ptr(wp), L.ptr(dimg), B, H, W, 16, ops.st))
+    assert _rel(dimg.cpu(), x.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 7, 7, 72, 24), (3, 5, 5, 160, 960), (2, 14, 14, 16, 64), (1, 28, 28, 40, 120)])
+def test_pointwise_conv_backward_mobilenet_widths(B, H, W, cin, cout):
+    """1x1 convolution at the MobileNet widths (not multiples of the 32-channel K chunk / 128-wide tile): forward, data gradient through the
+    transposed weight (+ skip gradient in the epilogue), weight gradient"""
+    E, ops = _enc_ops()
+    g = _gen(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 1, 1, generator=g) * 0.2)
+    conv = conv.cuda()
+    xs, x64 = _act(torch.randn(B, H, W, cin, generator=g))
+    ds, d64 = _act(torch.randn(B, H, W, cout, generator=g))
+    as_, a64 = _act(torch.randn(B, H, W, cin, generator=g))
+    from smirk_amd.smirk_generator import split16_to_float
+    w64 = split16_to_float(E._pw(conv).reshape(1, 1, cout, cin)).reshape(cout, cin, 1, 1).cpu().double().requires_grad_(True)
+    x = x64.clone().requires_grad_(True)
+    zr = F.conv2d(x, w64)
+    z = ops.pointwise(xs, E._pw(conv), cout)
+    assert _rel(_val(z), zr.detach()) < TOL
+    zr.backward(d64)
+    dx = ops.pointwise(ds, E._pw_t(conv), cin, residual=as_)
+    assert _rel(_val(dx), x.grad + a64) < TOL
+    dw = ops.wgrad(ds, xs, B, H, W, cout, cin, 1)
+    assert _rel(dw.reshape(cout, cin, 1, 1).cpu(), w64.grad) < TOL
+
+
+@pytest.mark.parametrize("B,hw,C,N", [(3, 9, 960, 55), (2, 49, 576, 6), (5, 4, 960, 300)])
+def test_pool_linear_head_backward(B, hw, C, N):
+    E, ops = _enc_ops()
+    from smirk_amd import _lib as L
+    g = _gen(C + N)
+    h = int(hw ** 0.5)
+    fs, f64 = _act(torch.randn(B, h, h, C, generator=g))
+    wt, bias = torch.randn(N, C, generator=g) * 0.05, torch.randn(N, generator=g)
+    wg, bg = wt.cuda().contiguous(), bias.cuda().contiguous()
+    pooled, out = torch.empty(B, C, device="cuda"), torch.empty(B, N, device="cuda")
+    L.check(ops.lib.smirk_gap_linear_split16(L.ptr(fs), L.ptr(wg), L.ptr(bg), L.ptr(out), L.ptr(pooled), B, h * h, C, N, ops.st))
+    f = f64.clone().requires_grad_(True)
+    w64, b64 = wt.double().requires_grad_(True), bias.double().requires_grad_(True)
+    o = F.linear(F.adaptive_avg_pool2d(f, 1).flatten(1), w64, b64)
+    assert _rel(out.cpu(), o.detach()) < TOL
+    go = torch.randn(B, N, generator=g)
+    o.backward(go.double())
+    dw, db, df = torch.empty(N, C, device="cuda"), torch.empty(N, device="cuda"), torch.empty(B, h, h, C, device="cuda")
+    L.check(ops.lib.smirk_gap_linear_backward_split16(L.ptr(go.cuda().contiguous()), L.ptr(wg), L.ptr(pooled), L.ptr(dw), L.ptr(db), L.ptr(df), B, h * h, C, N,
+                                                      ops.st))
+    assert _rel(dw.cpu(), w64.grad) < TOL and _rel(db.cpu(), b64.grad) < TOL and _rel(_val(df), f.grad) < TOL
