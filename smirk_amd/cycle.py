@@ -1,0 +1,102 @@
+"""The compute of the reference trainer's cycle path (BASELINE config 5; smirk_trainer.py:184-332 `step2`, :349-382 `step`) over the smirk_amd modules.
+
+The trainer itself — parameter augmentation, dataset, logging, optimiser schedule — is the reference's and stays the reference's (caller of
+the hot path, out of scope).  What it asks of the four modules per step is restated here so that tests and bench.py can drive exactly that sequence:
+
+    with no_grad:   FLAME(encoder_output), Renderer(...)                       smirk_trainer.py:247-249   (sampling of the source points)
+                    FLAME(augmented params), Renderer(...)  -> rendered        smirk_trainer.py:252-254
+                    mesh_based_mask_uniform_faces x2, transfer_pixels, mask    smirk_trainer.py:262-289
+    masking(...)    -> masked image                                            smirk_trainer.py:290-291
+    generator(cat[rendered, masked])          TRAIN mode (batch-statistic BN)  smirk_trainer.py:293
+    encoder(reconstructed)                    TRAIN mode                       smirk_trainer.py:297
+    FLAME / Renderer of the re-encoded parameters (visualisation only)         smirk_trainer.py:299-300
+    cycle loss = mse(exp) + 10 mse(jaw) + 10 mse(eyelid) [+ mse(shape)]        smirk_trainer.py:304-313
+    backward; clip_grad_norm_(generator, 0.1); optimiser steps                 smirk_trainer.py:367-376
+
+Multi-GPU (SURVEY.md §8(e) "C2"): batch-sharded data parallel, gradients averaged with ONE bucketed RCCL all-reduce per dtype after backward
+(`allreduce_gradients`); xGMI is point-to-point, so few large buckets (default 64 MiB: the generator's 125 MB of fp32 gradients go out as two) rather than
+per-parameter calls.  BatchNorm statistics stay per rank, like torch DDP without SyncBatchNorm (the reference has no DDP wrapper at all).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def cycle_loss(recon_feats, flame_feats, use_eyelids=True, generator_frozen=False):
+    """smirk_trainer.py:304-313"""
+    loss = 1.0 * F.mse_loss(recon_feats['expression_params'], flame_feats['expression_params']) + \
+        10.0 * F.mse_loss(recon_feats['jaw_params'], flame_feats['jaw_params'])
+    if use_eyelids:
+        loss = loss + 10.0 * F.mse_loss(recon_feats['eyelid_params'], flame_feats['eyelid_params'])
+    if not generator_frozen:
+        loss = loss + 1.0 * F.mse_loss(recon_feats['shape_params'], flame_feats['shape_params'])
+    return loss
+
+
+def render_second_path(flame, renderer, encoder_output, flame_feats, img, masks, face_probabilities, masking_utils, mask_ratio=0.01,
+                       mask_dilation_radius=10, Ke=1):
+    """smirk_trainer.py:245-291: everything between the augmented parameters and the generator's input.  Returns (rendered, masked)."""
+    with torch.no_grad():
+        flame_output = flame.forward(encoder_output)
+        rendered_output = renderer.forward(flame_output['vertices'], encoder_output['cam'])
+        flame_output.update(rendered_output)
+        flame_output_2nd = flame.forward(flame_feats)
+        cam = encoder_output['cam'] if Ke == 1 else encoder_output['cam'].repeat(Ke, 1)
+        renderer_output_2nd = renderer.forward(flame_output_2nd['vertices'], cam)
+        rendered_2nd = renderer_output_2nd['rendered_img'].detach()
+        points1, coords = masking_utils.mesh_based_mask_uniform_faces(flame_output['transformed_vertices'], flame_faces=flame.faces_tensor,
+                                                                      face_probabilities=face_probabilities, mask_ratio=mask_ratio)
+        coords['sampled_faces_indices'] = coords['sampled_faces_indices'].repeat(Ke, 1)
+        coords['barycentric_coords'] = coords['barycentric_coords'].repeat(Ke, 1, 1)
+        points2, coords = masking_utils.mesh_based_mask_uniform_faces(renderer_output_2nd['transformed_vertices'], flame_faces=flame.faces_tensor,
+                                                                      face_probabilities=face_probabilities, mask_ratio=mask_ratio, coords=coords)
+        extra_points = masking_utils.transfer_pixels(img.repeat(Ke, 1, 1, 1), points1.repeat(Ke, 1, 1), points2)
+        rendered_mask = (rendered_2nd > 0).all(dim=1, keepdim=True).float()
+    masked_2nd = masking_utils.masking(img.repeat(Ke, 1, 1, 1), masks.repeat(Ke, 1, 1, 1), extra_points, mask_dilation_radius, rendered_mask=rendered_mask,
+                                       extra_noise=True, random_mask=0.005)
+    return rendered_2nd, masked_2nd
+
+
+def cycle_forward(generator, encoder, rendered, masked, flame_feats, freeze_generator=False, use_eyelids=True):
+    """smirk_trainer.py:293-313: generator -> encoder -> cycle loss.  Returns (loss, reconstructed image, re-encoded parameters)."""
+    recon = generator(torch.cat([rendered, masked], dim=1).detach())
+    if freeze_generator:
+        recon = recon.detach()
+    feats = encoder(recon)
+    return cycle_loss(feats, flame_feats, use_eyelids, freeze_generator), recon, feats
+
+
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True):
+    """Data-parallel gradient exchange (C2): flatten the gradients into few large buckets, one all-reduce each (RCCL over xGMI on GPUs, gloo in the
+    CPU tests), scatter back.  Parameters without a gradient on this rank are skipped on EVERY rank only if they are skipped everywhere — the trainer
+    freezes the same modules on all ranks, and the bucket layout is derived from `requires_grad`, not from `.grad is None`, so ranks cannot disagree."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    todo = [p for p in params if p.requires_grad]
+    buckets, cur, size = [], [], 0
+    for p in todo:
+        n = p.numel() * p.element_size()
+        if cur and (size + n > bucket_bytes or p.dtype != cur[0].dtype):
+            buckets.append(cur); cur, size = [], 0
+        cur.append(p); size += n
+    if cur:
+        buckets.append(cur)
+    handles = []
+    for b in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+        handles.append((b, flat, dist.all_reduce(flat, group=group, async_op=True)))
+    for b, flat, h in handles:
+        h.wait()
+        if average:
+            flat.div_(world)
+        o = 0
+        for p in b:
+            n = p.numel()
+            g = flat[o:o + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += n
+    return len(buckets)

@@ -362,3 +362,16 @@ def test_video_convex_hull_agrees_with_scipy():
         mine = {tuple(p) for p in V.convex_hull(pts).tolist()}
         ref = {tuple(pts[i].tolist()) for i in ConvexHull(pts.astype(np.float64)).vertices}
         assert mine == ref
+
+
+def test_cycle_loss_formula_reproduces_the_reference_run(golden_dir):
+    """smirk_amd/cycle.py::cycle_loss (smirk_trainer.py:304-313) on the re-encoded parameters the REAL reference classes produced == the loss they produced"""
+    from oracle import make_cycle_golden as MC
+    from smirk_amd.cycle import cycle_loss
+    g = np.load(os.path.join(golden_dir, "cycle_golden.npz"))
+    _, _, feats = MC.inputs()
+    out = {k[len("out64/"):]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith("out64/")}
+    loss = cycle_loss(out, {k: v.double() for k, v in feats.items()}, use_eyelids=True, generator_frozen=False)
+    assert abs(loss.item() - float(g["loss64"])) < 2e-6 * float(g["loss64"])
+    frozen = cycle_loss(out, {k: v.double() for k, v in feats.items()}, generator_frozen=True)       # :310-311 the shape term only without the freeze
+    assert frozen.item() < loss.item()

@@ -80,3 +80,45 @@ def test_bench_self_launch_world2_gloo_plumbing():
     r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--plumbing-test"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, cwd=repo)
     assert r2.returncode != 0 and b"WORLD_SIZE=1" in r2.stderr
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smirk_amd.cycle import allreduce_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    for p in net[1].parameters():
+        p.requires_grad_(False)                                    # a frozen module in the middle (pose / shape encoders)
+    x = torch.arange(14, dtype=torch.float32).reshape(2, 7) * (rank + 1)
+    net(x).sum().backward()
+    net[2].bias.grad = None                                        # a trainable parameter that happened to get no gradient on this rank
+    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    nb = allreduce_gradients(list(net.parameters()), bucket_bytes=64)     # tiny buckets: several all-reduces
+    q.put((rank, nb, local, [None if p.grad is None else p.grad.clone() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_buckets_and_frozen_parameters():
+    """C2: bucketed gradient averaging; frozen parameters are left out, missing gradients count as zero"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+    (_, nb0, l0, a0), (_, nb1, l1, a1) = res
+    assert nb0 == nb1 and nb0 >= 2
+    for i, (x0, x1, y0, y1) in enumerate(zip(l0, l1, a0, a1)):
+        if i in (2, 3):                                            # the frozen layer
+            assert y0 is None and y1 is None
+            continue
+        z0 = x0 if x0 is not None else torch.zeros_like(y0)
+        z1 = x1 if x1 is not None else torch.zeros_like(y1)
+        assert torch.allclose(y0, (z0 + z1) / 2) and torch.equal(y0, y1)
