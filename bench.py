@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — faces/sec of SMIRK's per-frame hot path (encode -> FLAME -> render -> generate) at 224x224 on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|infer256|flame512] [--global-batch G | --batch B_PER_GPU]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|infer256|flame512|train64] [--global-batch G | --batch B_PER_GPU]
 
 `--gpus N` with N > 1 launches itself as N ranks (one process per GPU, torch.distributed.run, rendezvous on 127.0.0.1); when the driver
 already started it under torch.distributed.run (RANK / WORLD_SIZE set) it just joins.
@@ -42,6 +42,9 @@ sys.path.insert(0, REPO)
 FLOP_PER_FACE = 28.77e9          # encoder 0.929 G + FLAME 12.7 M + render ~2 M + generator 27.826 G
 FLOP_PER_FACE_INFER = 0.929e9 + 12.7e6 + 2e6
 FLOP_PER_FACE_FLAME = 12.7e6
+# config 5 (cycle-path training step): generator forward + data gradient + weight gradient (3 x 27.826 G), the three encoders forward (0.929 G), the
+# expression encoder's data + weight gradients and the shape encoder's data gradient (3 x ~0.41 G), FLAME + renderer three times
+FLOP_PER_FACE_TRAIN = 3 * 27.826e9 + 0.929e9 + 3 * 0.41e9 + 3 * 14.7e6
 PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA = 2500e12          # MI355X_MICROARCH.md: bf16/fp16 dense MFMA peak (the f16x3 kernel issues 3 MFMA-flop per algorithmic flop)
 PEAK_HBM = 8.0e12
@@ -49,7 +52,8 @@ MICRO_BATCH = 167                # frames per pass of the path: fills whole roun
                                  # layers (activations ~11 GB per pass; 32-bit buffer offsets stay valid up to 325 frames)
 METRIC = {"full": "faces/sec (encode+FLAME+render+generate) @224x224",
           "infer256": "faces/sec (encode+FLAME+render) @224x224",
-          "flame512": "faces/sec (FLAME-only: shape,exp,pose,jaw -> 5023 vertices)"}
+          "flame512": "faces/sec (FLAME-only: shape,exp,pose,jaw -> 5023 vertices)",
+          "train64": "faces/sec (cycle-path training step: render + generate + re-encode + cycle loss + backward + optimiser) @224x224"}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -60,7 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("full", "infer256", "flame512"), default="full")
+    ap.add_argument("--workload", choices=("full", "infer256", "flame512", "train64"), default="full")
     ap.add_argument("--global-batch", type=int, default=None, help="frames per step over ALL GPUs (strong scaling; default 1024 / 256 / 512 by workload)")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (weak scaling; overrides --global-batch)")
     ap.add_argument("--micro-batch", type=int, default=None,
@@ -162,6 +166,54 @@ def cpu_baseline(sandbox, workload, n_faces):
     os.environ["OMP_NUM_THREADS"] = str(nthr)
     fr = FlameRef(sandbox)
     stages = {}
+    if workload == "train64":
+        # the cycle path on the CPU oracle: numpy FLAME + C rasteriser (x3), torch-CPU autograd through the restated generator and encoders in train mode
+        import torch.nn.functional as F
+        n_faces = min(n_faces, 8)
+        rr = RendererRef(sandbox)
+        encr = M.SmirkEncoderRef(); encr.load_state_dict(M.synth_encoder_state_dict()); encr.train()
+        for m in (encr.pose_encoder, encr.shape_encoder):
+            for p in m.parameters():
+                p.requires_grad_(False)
+        gsd = G.synth_state_dict()
+        gp, gb = G.split_state_dict(gsd)
+        fp = synth.synth_flame_params(n_faces, seed=5)
+        cam = synth.synth_cam(n_faces, seed=5)
+        masked = synth.synth_generator_input(n_faces, seed=5)[:, 3:]
+        tgt = dict(expression_params=torch.randn(n_faces, 50), jaw_params=torch.rand(n_faces, 3) * .2, eyelid_params=torch.rand(n_faces, 2),
+                   shape_params=torch.randn(n_faces, 300) * .5)
+
+        def run():
+            t0 = time.perf_counter()
+            for _ in range(2):                                     # the encoder estimate and the augmented parameters
+                r = rr.forward(fr.forward(fp)["vertices"], cam)
+            t1 = time.perf_counter()
+            y = G.train_forward(gp, gb, torch.cat([torch.from_numpy(r["rendered_img"]), masked], 1))
+            o = encr(y)
+            loss = F.mse_loss(o["expression_params"], tgt["expression_params"]) + 10 * F.mse_loss(o["jaw_params"], tgt["jaw_params"]) + \
+                10 * F.mse_loss(o["eyelid_params"], tgt["eyelid_params"]) + F.mse_loss(o["shape_params"], tgt["shape_params"])
+            t2 = time.perf_counter()
+            for p in list(gp.values()) + list(encr.parameters()):
+                p.grad = None
+            loss.backward()
+            t3 = time.perf_counter()
+            pn = {k: v.detach().numpy() for k, v in o.items()}
+            pn["cam"] = np.clip(pn["cam"], [6, -.1, -.1], [10, .1, .1]).astype(np.float32)
+            rr.forward(fr.forward(pn)["vertices"], pn["cam"])
+            stages.update(flame_render_x2=t1 - t0, forward=t2 - t1, backward=t3 - t2, flame_render_reencoded=time.perf_counter() - t3)
+
+        run()
+        times, keep = [], {}
+        for _ in range(3):
+            t = time.perf_counter()
+            run()
+            times.append(time.perf_counter() - t)
+            keep = dict(stages) if times[-1] <= min(times) else keep
+        med = statistics.median(times)
+        return {"value": n_faces / med, "unit": "faces/sec", "cores": nthr, "kind": "port", "host_cores": os.cpu_count(),
+                "stage_seconds": {k: round(v, 4) for k, v in keep.items()},
+                "sample": f"{n_faces} synthetic frames through the CPU oracle's cycle step (numpy FLAME + C rasteriser x3, torch-CPU fp32 autograd through the "
+                          f"restated generator and encoders in train mode, no optimiser step; {nthr} threads), 1 warm-up + 3 timed passes, median {med:.2f} s"}
     if workload == "flame512":
         p = synth.synth_flame_params(n_faces, seed=5)
 
@@ -266,7 +318,9 @@ def measure_traffic(args):
 def per_rank_batch(args, world):
     if args.batch is not None:
         return args.batch
-    g = args.global_batch or {"full": 1024, "infer256": 256, "flame512": 512}[args.workload]
+    if args.workload == "train64" and args.global_batch is None:
+        return 64                                                  # config 5 is 64 frames PER GPU (x8 data-parallel): weak scaling by definition
+    g = args.global_batch or {"full": 1024, "infer256": 256, "flame512": 512, "train64": 64}[args.workload]
     return max(1, g // world)
 
 
@@ -391,6 +445,65 @@ class FlameWorkload(Workload):
     instrumented = step
 
 
+class TrainWorkload(Workload):
+    """BASELINE config 5: the cycle path of smirk_trainer.py:184-332 + the backward / clip / optimiser part of `step` (:365-376), 64 frames per GPU.
+    The parameter augmentation (random draws on [B, 50] tensors, trainer code) is done once at set-up; everything the four modules compute per step is
+    inside step(): FLAME + renderer of the encoder estimate and of the augmented parameters, point sampling / pixel transfer / masking, generator and
+    encoders in TRAIN mode, FLAME + renderer of the re-encoded parameters, cycle loss, backward, gradient all-reduce (N > 1), clip, two Adam steps."""
+    keys = ("reconstructed_img", "loss")
+
+    def __init__(self, args, dev, rank, world, sandbox):
+        import torch
+        from smirk_amd import masking as MK, synth
+        enc, flame, rend, gen = build_modules(sandbox, dev)
+        self.enc, self.flame, self.rend, self.gen, self.MK = enc, flame, rend, gen, MK
+        cwd = os.getcwd(); os.chdir(sandbox)
+        try:
+            self.face_prob = MK.load_probabilities_per_FLAME_triangle().to(dev)
+        finally:
+            os.chdir(cwd)
+        self.B = B = per_rank_batch(args, world)
+        self.slices = [(0, B)]
+        chunks = [(i, min(i + 32, B)) for i in range(0, B, 32)]
+        self.img = torch.cat([synth.synth_images(hi - lo, seed=5000 + 97 * rank + lo).to(dev) for lo, hi in chunks])
+        self.mask = torch.cat([(synth.synth_generator_input(hi - lo, seed=5000 + 97 * rank + lo)[:, 3:4] != 0).float().contiguous().to(dev) for lo, hi in chunks])
+        with torch.no_grad():                                        # step1's encoder estimate (smirk_trainer.py:95-96), detached as step2 receives it
+            self.enc_out = {k: v.detach().clone() for k, v in enc(self.img).items()}
+        g = torch.Generator(device="cpu").manual_seed(6000 + rank)
+        f = {k: v.clone() for k, v in self.enc_out.items()}
+        f["expression_params"] = (f["expression_params"] + 0.5 * torch.randn(B, f["expression_params"].shape[1], generator=g).to(dev)).clamp(-4, 4)
+        f["jaw_params"] = f["jaw_params"] + 0.05 * torch.randn(B, 3, generator=g).to(dev) * torch.tensor([1., .1, .1], device=dev)
+        f["jaw_params"][:, 0].clamp_(0.0, 0.5)
+        f["eyelid_params"] = (f["eyelid_params"] + 0.25 * (2 * torch.rand(B, 2, generator=g).to(dev) - 1)).clamp(0, 1)
+        self.feats = f
+        enc.train(); gen.train()
+        for m in (enc.pose_encoder, enc.shape_encoder):              # config_train.yaml:41-43: only the expression encoder is optimised
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.enc_params = [p for p in enc.parameters() if p.requires_grad]
+        self.gen_params = list(gen.parameters())
+        self.opt_e = torch.optim.Adam(self.enc_params, lr=0.25e-3)   # base_trainer.py:36-55
+        self.opt_g = torch.optim.Adam(self.gen_params, lr=1e-3)
+        self.world = world
+        self.buckets = 0
+
+    def step(self):
+        import torch
+        from smirk_amd.cycle import allreduce_gradients, cycle_forward, render_second_path
+        rendered, masked = render_second_path(self.flame, self.rend, self.enc_out, self.feats, self.img, self.mask, self.face_prob, self.MK)
+        loss, recon, rf = cycle_forward(self.gen, self.enc, rendered, masked, self.feats)
+        fo = self.flame.forward(rf)                                  # smirk_trainer.py:299-300 (feeds the visualisation grid only)
+        self.rend.forward(fo['vertices'], rf['cam'])
+        self.opt_e.zero_grad(set_to_none=True); self.opt_g.zero_grad(set_to_none=True)
+        loss.backward()
+        self.buckets = allreduce_gradients(self.enc_params + self.gen_params)
+        torch.nn.utils.clip_grad_norm_(self.gen_params, 0.1)
+        self.opt_e.step(); self.opt_g.step()
+        self.last = {"reconstructed_img": recon.detach(), "loss": loss.detach().reshape(1)}
+
+    instrumented = step
+
+
 class PlumbingWorkload(Workload):
     """CPU/gloo stand-in for the path used ONLY by tests/test_distributed_cpu.py to drive this script's rank / shard / micro-batch /
     gather / timing bookkeeping end to end without a GPU.  It computes nothing of SMIRK and its JSON line is labelled as such."""
@@ -489,7 +602,7 @@ def main():
 
     from smirk_amd import _lib as L
     sandbox = tempfile.mkdtemp(prefix=f"smirk_bench_r{rank}_")
-    cls = PlumbingWorkload if args.plumbing_test else {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload}[args.workload]
+    cls = PlumbingWorkload if args.plumbing_test else {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload, "train64": TrainWorkload}[args.workload]
     wl = cls(args, dev, rank, world, sandbox)
 
     def sync():
@@ -567,23 +680,29 @@ def main():
         cpu = None
         if world == 1 and args.cpu_faces > 0 and not args.plumbing_test:
             cpu = cpu_baseline(sandbox, args.workload, args.cpu_faces if args.workload != "flame512" else 512)
-        weak = args.batch is not None
-        flop_face = {"full": FLOP_PER_FACE, "infer256": FLOP_PER_FACE_INFER, "flame512": FLOP_PER_FACE_FLAME}[args.workload]
+        weak = args.batch is not None or (args.workload == "train64" and args.global_batch is None)
+        flop_face = {"full": FLOP_PER_FACE, "infer256": FLOP_PER_FACE_INFER, "flame512": FLOP_PER_FACE_FLAME, "train64": FLOP_PER_FACE_TRAIN}[args.workload]
         gen_prec = getattr(getattr(wl, "gen", None), "precision", None)
         line = {
             "metric": METRIC[args.workload] if not args.plumbing_test else "PLUMBING TEST (CPU stub of the path; not a measurement)",
             "value": value, "unit": "faces/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": ("f32 results; encoder + generator convs as split-fp16 x3 MFMA with f32 accumulate (fp32-class error), FLAME / raster f32"
+            "dtype": ("f32-class throughout (reference config: bf16 autocast): convolutions and their data gradients as split-fp16 x3 MFMA with f32 accumulate, weight "
+                      "gradients exact f32 MFMA, BatchNorm statistics f64, FLAME / raster f32, Adam f32" if args.workload == "train64" else
+                      "f32 results; encoder + generator convs as split-fp16 x3 MFMA with f32 accumulate (fp32-class error), FLAME / raster f32"
                       if gen_prec == "f16x3" or args.workload == "infer256" else "f32"),
             "data": "synthetic",
             "config": {"workload": {"full": "BASELINE config 4: full inference incl. SmirkGenerator re-synthesis, 1024-frame batch sharded over the GPUs",
                                     "infer256": "BASELINE config 3: full inference (encoder + FLAME + renderer), batch 256",
-                                    "flame512": "BASELINE config 2: FLAME-only, batch 512 random (shape, exp, pose, jaw, eyelid) -> 5023 vertices"}[args.workload],
+                                    "flame512": "BASELINE config 2: FLAME-only, batch 512 random (shape, exp, pose, jaw, eyelid) -> 5023 vertices",
+                                    "train64": "BASELINE config 5: smirk_trainer.py cycle-path training step (render + generate + re-encode + losses + backward + "
+                                               "clip + Adam), 64 frames per GPU, data-parallel"}[args.workload],
                        "frames_per_gpu_per_step": B, "global_batch": B * world, "micro_batch": min(args.micro_batch, B), "image": "224x224",
                        "parallelism": f"dp{world}", "rccl_ranks_seen": ranks_seen,
                        "collective": ("async all_gather_into_tensor(vertices, rendered_img, reconstructed_img) per micro-batch" if world > 1 else "none (1 GPU)")
-                       if args.workload == "full" or args.plumbing_test else "none (outputs stay on the rank)",
+                       if args.workload == "full" or args.plumbing_test else
+                       (f"bucketed all_reduce of the gradients after backward ({getattr(wl, 'buckets', 0)} buckets of <= 64 MiB)" if world > 1 else "none (1 GPU)")
+                       if args.workload == "train64" else "none (outputs stay on the rank)",
                        "weights": "random-init (He) reference architecture, encoder heads rescaled to the trained network's parameter ranges; no checkpoint offline; outputs asserted finite",
                        **({"masking": "given masked image" if args.given_masked else
                            "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",

@@ -385,6 +385,10 @@ int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const float* y, cons
 /* Weight gradient of a KHxKH (1 or 3), stride-1, pad-(KH-1)/2 (zero or reflect) convolution in exact fp32 (v_mfma_f32_32x32x2_f32):
  * dw[Cout][(ky,kx,ci)] = sum_p dz[p][co] * x[p + (ky,kx) - pad][ci]   — the packed forward weight layout.  ConvTranspose2d(k=2,s=2): call with KH = 1,
  * dz = the layer INPUT [M][Cin_t] and x = space_to_depth2(output gradient) [M][4*Cout_t] => dw[Cin_t][(dy,dx,co)]. */
+/* nn.Conv2d weight [Cout][cin_total][KH][KH] fp32 (KH 1 or 3), input-channel slice [cin_off, cin_off + Cin) (a U-Net decoder conv reads two sources)
+ * -> the step's two split16 operand images in ONE launch (either may be NULL):
+ * fwd [Cout][(ky,kx,c)], c < cin_pad (zeros beyond Cin) and dgrad [cin_pad][(ky,kx,co)] = W rotated by 180 degrees with Cin <-> Cout swapped. */
+int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin_total, int cin_off, int Cin, int KH, int cin_pad, void* fwd, void* dgrad, void* stream);
 size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, int KH);
 int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                          void* stream);

@@ -137,6 +137,7 @@ _SIGS = {
     "smirk_conv1x1_sigmoid_backward_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_pack_conv_weights_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_stem_conv_s2_raw_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_stem_conv_s2_wgrad_workspace_bytes": (_sz, [_i]),
     "smirk_stem_conv_s2_wgrad_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),

@@ -29,6 +29,10 @@ __device__ __forceinline__ void store_group(float* p, const float* v) {
     *(half8*)(p + 4) = lo;
 }
 
+inline unsigned row_blocks(size_t M, int RPB) {                             // blocks of 256 / G rows, about 8 per CU at most
+    const size_t b = (M + RPB - 1) / RPB;
+    return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
+}
 inline unsigned blocks_for(size_t items, unsigned cap) {
     const size_t g = (items + 255) / 256;
     return (unsigned)(g > cap ? cap : (g ? g : 1));
@@ -87,14 +91,28 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
     }
 }
 
-// stage 2 of MODE 0: mean, biased variance, invstd, running-stat update (momentum; running_var takes the unbiased variance)
+// stage 2: the <= 512 per-block partials of a channel are summed by 16 threads (strided, fixed order) and combined in LDS in a fixed order;
+// one workgroup = 16 channels x 16 partial lanes.  (A single thread per channel walking 512 partials was 0.1 ms of pure load latency per launch.)
+__device__ __forceinline__ bool stage2_sum(const double* __restrict__ part, int nblocks, int C, int c, double& a, double& b, double (*red)[16][2]) {
+    const int j = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    double sa = 0.0, sb = 0.0;
+    if (c < C)
+        for (int k = j; k < nblocks; k += 16) { sa += part[((size_t)k * C + c) * 2]; sb += part[((size_t)k * C + c) * 2 + 1]; }
+    red[j][cl][0] = sa; red[j][cl][1] = sb;
+    __syncthreads();
+    if (j != 0 || c >= C) return false;
+    a = 0.0; b = 0.0;
+    for (int k = 0; k < 16; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
+    return true;
+}
+// MODE 0: mean, biased variance, invstd, running-stat update (momentum; running_var takes the unbiased variance)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblocks, int C, double n, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblocks; ++k) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    double a, b;
+    if (!stage2_sum(part, nblocks, C, c, a, b, red)) return;
     const double m = a / n;
     double v = b / n - m * m;
     if (v < 0.0) v = 0.0;
@@ -103,31 +121,38 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
 }
 
-// stage 2 of MODE 1 / plain column sums: out1[c] = S1, out2[c] = S2 (as fp32)
+// MODE 1 / plain column sums: out1[c] = S1, out2[c] = S2 (as fp32)
 __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ part, int nblocks, int C, float* __restrict__ out1, float* __restrict__ out2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblocks; ++k) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    double a, b;
+    if (!stage2_sum(part, nblocks, C, c, a, b, red)) return;
     if (out1) out1[c] = (float)a;
     if (out2) out2[c] = (float)b;
 }
 
+// The two BatchNorm element-wise kernels give every thread a FIXED 8-channel group and let it walk rows (256 / G rows in flight per block), so
+// the per-channel coefficients are loaded once into registers and no per-element index division is needed.
 // y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t NG, int G, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ residual, int relu, float* __restrict__ y) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NG; i += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % G);
+    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
+    if (rl >= RPB) return;
+    float mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
+    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
+        const size_t i = r * G + g;
         float v[8];
         load_group(z + i * 8, v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mean[g * 8 + q]) * invstd[g * 8 + q] * gamma[g * 8 + q] + beta[g * 8 + q];
+        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mu[q]) * is[q] * ga[q] + be[q];
         if (residual) {
-            float r[8];
-            load_group(residual + i * 8, r);
+            float rr[8];
+            load_group(residual + i * 8, rr);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += r[q];
+            for (int q = 0; q < 8; ++q) v[q] += rr[q];
         }
         if (relu) {
 #pragma unroll
@@ -138,22 +163,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // dz = gamma * invstd * (dyh - sum_dyh / n - xhat * sum_dyh_xhat / n)
-__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t NG, int G, float inv_n,
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
                                                                 float* __restrict__ dz) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NG; i += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % G);
+    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
+    if (rl >= RPB) return;
+    float mu[8], is[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = g * 8 + q;
+        mu[q] = mean[c]; is[q] = invstd[c]; ga[q] = gamma[c]; be[q] = beta[c]; s1[q] = sum_dy[c] * inv_n; s2[q] = sum_dy_xhat[c] * inv_n;
+    }
+    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
+        const size_t i = r * G + g;
         float v[8], d[8];
         load_group(z + i * 8, v);
         load_group(dy + i * 8, d);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int c = g * 8 + q;
-            const float xh = (v[q] - mean[c]) * invstd[c];
-            const float dh = (relu && !(xh * gamma[c] + beta[c] > 0.f)) ? 0.f : d[q];
-            v[q] = gamma[c] * invstd[c] * (dh - sum_dy[c] * inv_n - xh * sum_dy_xhat[c] * inv_n);
+            const float xh = (v[q] - mu[q]) * is[q];
+            const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[q];
+            v[q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
         }
         store_group(dz + i * 8, v);
     }
@@ -285,13 +317,16 @@ __global__ __launch_bounds__(256) void final_backward_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Weight gradient:  dW[co][tap][ci] = sum over pixels p of dZ[p][co] * X[p shifted by tap][ci]     (exact fp32 on v_mfma_f32_32x32x2_f32)
-//   workgroup = 128 (co) x 128 (ci) tile of one tap, one K split of the pixel range; 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA blocks;
-//   16 pixels per chunk staged as fp32 [k][128 + 4] in LDS (decoded from split16), fragment = one ds_read_b32 per lane and MFMA.
-// part[split][Cout][KH*KW][Cin] fp32 partials are summed in split order by wgrad_reduce_kernel  (bit-reproducible).
+// Weight gradient:  dW[co][n] = sum over pixels p of dZ[p][co] * X[p shifted by tap(n)][ci(n)],  n = tap * Cin + ci     (exact fp32, v_mfma_f32_32x32x2_f32)
+//   GEMM with M = Cout, N = KH*KH*Cin (the taps are flattened INTO N, so a 32-channel layer still fills a 128-wide tile with four taps) and
+//   K = B*H*W pixels split over gridDim.z.  Workgroup tile TM x 128 with TM in {32, 64, 128} chosen from Cout; 4 waves as 2 x 2 (TM = 128: 64 x 64 per
+//   wave) or 1 x 4 (TM <= 64: TM x 32 per wave).  16 pixels per chunk, decoded from split16 into fp32 [k][TM + 4] / [k][128 + 4] in a DOUBLE-BUFFERED LDS
+//   image: the next chunk's global loads are issued before the current chunk's MFMAs and land in registers underneath them; one barrier per chunk.
+// part[split][Cout][N] fp32 partials are summed in split order by wgrad_reduce_kernel  (bit-reproducible).
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define WG_KC 16
 #define WG_LD 132
+#define WG_MAX_SPLIT 512
 struct WgradArgs {
     const float *dz, *x;         // split16 [B][H][W][Cout], [B][H][W][Cin]
     float* part;
@@ -299,34 +334,40 @@ struct WgradArgs {
     int chunks_per_split;        // 16-pixel chunks per K split
 };
 
+template <int TM>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[WG_KC * WG_LD], Bs[WG_KC * WG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int ntaps = a.KH * a.KH;
-    const int cot = blockIdx.x, cit = blockIdx.y % ((a.Cin + 127) / 128), tap = blockIdx.y / ((a.Cin + 127) / 128), split = blockIdx.z;
-    const int ky = tap / a.KH, kx = tap % a.KH;
-    const int co0 = cot * 128, ci0 = cit * 128;
+    constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
+    constexpr int BM = TM / 32 / WAVES_M, BN = 4 / WAVES_N;                 // 32 x 32 MFMA blocks per wave
+    constexpr int LDA = TM + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][WG_KC * LDA], Bs[2][WG_KC * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int N = a.KH * a.KH * a.Cin;
+    const int co0 = blockIdx.x * TM, n0 = blockIdx.y * 128, split = blockIdx.z;
     const long long npix = (long long)a.B * a.H * a.W;
-    f32x16 acc[2][2];
+    f32x16 acc[BM][BN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < BN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // staging: thread -> (pixel k = tid / 16, 8-channel group = tid % 16) of the 16 x 128 tile
+    // staging: thread -> (pixel k = tid / 16, 8-wide group = tid % 16) of the 16 x 128 B tile and (for tid % 16 < TM / 8) of the 16 x TM A tile
     const int sk = tid >> 4, sg = tid & 15;
     const int Gout = a.Cout / 8, Gin = a.Cin / 8;
-    for (int c = 0; c < a.chunks_per_split; ++c) {
+    const int gco = co0 / 8 + sg;
+    const bool a_on = sg < TM / 8 && gco < Gout;
+    const int nb = n0 + sg * 8;                                               // this thread's 8 B columns: one tap, 8 consecutive input channels
+    const bool b_on = nb < N;
+    const int tap = b_on ? nb / a.Cin : 0, gci = b_on ? (nb % a.Cin) / 8 : 0;
+    const int ky = tap / a.KH, kx = tap % a.KH;
+    float va[8], vb[8];
+    auto fetch = [&](int c) {
         const long long p = ((long long)split * a.chunks_per_split + c) * WG_KC + sk;
-        float va[8], vb[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { va[q] = 0.f; vb[q] = 0.f; }
         if (p < npix) {
-            const int gco = co0 / 8 + sg;
-            if (gco < Gout) load_group(a.dz + ((size_t)p * Gout + gco) * 8, va);
-            const int gci = ci0 / 8 + sg;
-            if (gci < Gin) {
+            if (a_on) load_group(a.dz + ((size_t)p * Gout + gco) * 8, va);
+            if (b_on) {
                 const int x0 = (int)(p % a.W), y0 = (int)((p / a.W) % a.H);
                 const long long b = p / ((long long)a.W * a.H);
                 int iy = y0 + ky - a.pad, ix = x0 + kx - a.pad;
@@ -336,42 +377,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 if (ok) load_group(a.x + ((((size_t)b * a.H + iy) * a.W + ix) * Gin + gci) * 8, vb);
             }
         }
-        __syncthreads();                                           // previous chunk's fragment reads are done
-        *(f32x4*)(As + sk * WG_LD + sg * 8) = *(f32x4*)va; *(f32x4*)(As + sk * WG_LD + sg * 8 + 4) = *(f32x4*)(va + 4);
-        *(f32x4*)(Bs + sk * WG_LD + sg * 8) = *(f32x4*)vb; *(f32x4*)(Bs + sk * WG_LD + sg * 8 + 4) = *(f32x4*)(vb + 4);
-        __syncthreads();
+    };
+    fetch(0);
+    for (int c = 0; c < a.chunks_per_split; ++c) {
+        float* as = As[c & 1];
+        float* bs = Bs[c & 1];
+        if (sg < TM / 8) { *(f32x4*)(as + sk * LDA + sg * 8) = *(f32x4*)va; *(f32x4*)(as + sk * LDA + sg * 8 + 4) = *(f32x4*)(va + 4); }
+        *(f32x4*)(bs + sk * WG_LD + sg * 8) = *(f32x4*)vb; *(f32x4*)(bs + sk * WG_LD + sg * 8 + 4) = *(f32x4*)(vb + 4);
+        __syncthreads();                       // chunk c visible; the buffer written next iteration was last read two iterations ago, behind this barrier
+        if (c + 1 < a.chunks_per_split) fetch(c + 1);
         const int kk = lane >> 5, mm = lane & 31;
 #pragma unroll
         for (int k2 = 0; k2 < WG_KC; k2 += 2) {
-            float fa[2], fb[2];
+            float fa[BM], fb[BN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = As[(k2 + kk) * WG_LD + (wm * 2 + i) * 32 + mm];
+            for (int i = 0; i < BM; ++i) fa[i] = as[(k2 + kk) * LDA + (wm * BM + i) * 32 + mm];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = Bs[(k2 + kk) * WG_LD + (wn * 2 + j) * 32 + mm];
+            for (int j = 0; j < BN; ++j) fb[j] = bs[(k2 + kk) * WG_LD + (wn * BN + j) * 32 + mm];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < BM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
-    float* out = a.part + (size_t)split * a.Cout * ntaps * a.Cin;
+    float* out = a.part + (size_t)split * a.Cout * N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ci = ci0 + (wn * 2 + j) * 32 + (lane & 31);
+        for (int j = 0; j < BN; ++j) {
+            const int n = n0 + (wn * BN + j) * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wm * 2 + i) * 32 + mfma32_row(r, lane);
-                if (co < a.Cout && ci < a.Cin) out[((size_t)co * ntaps + tap) * a.Cin + ci] = acc[i][j][r];
+                const int co = co0 + (wm * BM + i) * 32 + mfma32_row(r, lane);
+                if (co < a.Cout && n < N) out[(size_t)co * N + n] = acc[i][j][r];
             }
         }
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ dw) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-        dw[i] = s;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // 8 independent chains keep 8 loads in flight; combined in a fixed order
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += part[(size_t)(k + j) * n + i];
+        for (; k < nsplit; ++k) s[0] += part[(size_t)k * n + i];
+        dw[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    }
+}
+
+// One launch per convolution and training step: nn.Conv2d weight [Cout][Cin][KH][KH] fp32 -> the two split16 operand images the step needs,
+//   fwd  [Cout][(ky,kx,c)]        c < cin_pad (zero beyond Cin)                      : the forward implicit-GEMM weight
+//   dgr  [cin_pad][(ky',kx',co)]  = W[co][ci][KH-1-ky'][KH-1-kx'] (zero rows beyond Cin): the data-gradient convolution's weight (180-degree rotation,
+//                                                                                        Cin <-> Cout); for KH = 1 simply the transpose.
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, int Cout, int cin_total, int cin_off, int Cin, int KH, int cin_pad,
+                                                                float* __restrict__ fwd, float* __restrict__ dgr) {
+    const int T = KH * KH;
+    const size_t nf = (size_t)Cout * T * cin_pad / 8, nd = (size_t)cin_pad * T * Cout / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8];
+        if (i < nf) {
+            if (!fwd) continue;
+            const size_t k0 = (i * 8) % ((size_t)T * cin_pad);
+            const int co = (int)((i * 8) / ((size_t)T * cin_pad)), tap = (int)(k0 / cin_pad), c0 = (int)(k0 % cin_pad);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (c0 + q < Cin) ? w[((size_t)co * cin_total + cin_off + c0 + q) * T + tap] : 0.f;
+            store_group(fwd + i * 8, v);
+        } else {
+            if (!dgr) continue;
+            const size_t j = i - nf, k0 = (j * 8) % ((size_t)T * Cout);
+            const int ci = (int)((j * 8) / ((size_t)T * Cout)), tap = (int)(k0 / Cout), co0 = (int)(k0 % Cout);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (ci < Cin) ? w[((size_t)(co0 + q) * cin_total + cin_off + ci) * T + (T - 1 - tap)] : 0.f;
+            store_group(dgr + j * 8, v);
+        }
     }
 }
 
@@ -380,6 +458,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin_total, int cin_off, int Cin, int KH, int cin_pad, void* fwd, void* dgrad,
+                                               void* stream) {
+    if (!w || (!fwd && !dgrad) || Cout <= 0 || Cin <= 0 || cin_off < 0 || cin_off + Cin > cin_total || Cout % 8 || cin_pad % 8 || cin_pad < Cin ||
+        (KH != 1 && KH != 3))
+        return SMIRK_ERR_BAD_ARG;
+    const size_t n = ((size_t)Cout * KH * KH * cin_pad + (size_t)cin_pad * KH * KH * Cout) / 8;
+    SMIRK_LAUNCH(pack_conv_weights_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, w, Cout, cin_total, cin_off, Cin, KH, cin_pad, (float*)fwd, (float*)dgrad);
+    return smirk_launch_status();
+}
+
 extern "C" size_t smirk_train_reduce_workspace_bytes(int C) { return (size_t)RED_BLOCKS * (size_t)C * 2 * sizeof(double); }
 
 extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
@@ -393,10 +481,10 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
                  (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
-    SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
+    SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
                  save_invstd, running_mean, running_var);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
-    SMIRK_LAUNCH(bn_apply_kernel, dim3(blocks_for(M * G, 16384)), dim3(256), 0, st, (const float*)z, M * (size_t)G, G, (const float*)save_mean,
+    SMIRK_LAUNCH(bn_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, M, G, (const float*)save_mean,
                  (const float*)save_invstd, gamma, beta, (const float*)residual, relu, (float*)y);
     return smirk_launch_status();
 }
@@ -411,8 +499,9 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     const int G = C / 8, RPB = 256 / G;
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
-    SMIRK_LAUNCH(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
-    SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(blocks_for(M * G, 16384)), dim3(256), 0, st, (const float*)z, (const float*)dy, M * (size_t)G, G,
+    SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
+    smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
+    SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G,
                  (float)(1.0 / (double)M), save_mean, save_invstd, gamma, beta, (const float*)dbeta, (const float*)dgamma, relu, (float*)dz);
     return smirk_launch_status();
 }
@@ -425,7 +514,7 @@ extern "C" int smirk_colsum_split16(const void* x, size_t M, int C, float* sums,
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)x, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
                  (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
-    SMIRK_LAUNCH(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, sums, (float*)nullptr);
+    SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, sums, (float*)nullptr);
     return smirk_launch_status();
 }
 
@@ -458,10 +547,18 @@ extern "C" int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const flo
     return smirk_launch_status();
 }
 
+static int wgrad_nsplit(long long npix, int Cout, int N) {
+    const long long chunks = (npix + WG_KC - 1) / WG_KC;
+    const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
+    const long long tiles = (long long)((Cout + TM - 1) / TM) * ((N + 127) / 128);
+    long long want = (1024 + tiles - 1) / tiles;                       // ~4 workgroups per CU
+    if (want > WG_MAX_SPLIT) want = WG_MAX_SPLIT;
+    if (want > chunks) want = chunks;
+    return (int)(want < 1 ? 1 : want);
+}
 extern "C" size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, int KH) {
-    const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
-    long long nsplit = chunks < 64 ? chunks : 64;
-    return (size_t)nsplit * Cout * KH * KH * Cin * 4;
+    const long long npix = (long long)B * H * W;
+    return (size_t)wgrad_nsplit(npix, Cout, KH * KH * Cin) * Cout * KH * KH * Cin * 4;
 }
 /* dW[Cout][(ky,kx,ci)] (fp32, the packed forward layout) = sum over pixels of dz[p][co] * x[p + tap][ci];  KH in {1, 3}, pad = (KH-1)/2 */
 extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
@@ -469,15 +566,18 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
     if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || Cout % 8 || Cin % 8 || Cout <= 0 || Cin <= 0 || (KH != 1 && KH != 3)) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH)) return SMIRK_ERR_WORKSPACE;
     const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
-    const int nsplit = (int)(chunks < 64 ? chunks : 64);
+    const int N = KH * KH * Cin, nsplit = wgrad_nsplit(npix, Cout, N);
     WgradArgs a;
     a.dz = (const float*)dz; a.x = (const float*)x; a.part = (float*)ws;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.pad = (KH - 1) / 2; a.reflect = reflect;
     a.chunks_per_split = (int)((chunks + nsplit - 1) / nsplit);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((Cout + 127) / 128, ((Cin + 127) / 128) * KH * KH, nsplit);
-    smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * Cin * KH * KH, 0.0);
-    SMIRK_LAUNCH(wgrad_kernel, grid, dim3(256), 0, st, a);
+    const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
+    const dim3 grid((Cout + TM - 1) / TM, (N + 127) / 128, nsplit);
+    smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
+    if (TM == 32) SMIRK_LAUNCH(wgrad_kernel<32>, grid, dim3(256), 0, st, a);
+    else if (TM == 64) SMIRK_LAUNCH(wgrad_kernel<64>, grid, dim3(256), 0, st, a);
+    else SMIRK_LAUNCH(wgrad_kernel<128>, grid, dim3(256), 0, st, a);
     const size_t n = (size_t)Cout * KH * KH * Cin;
     SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, st, (const float*)ws, nsplit, n, dw);
     return smirk_launch_status();

@@ -130,9 +130,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_stage2(const double* __restrict_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * 9) return;
     const int c = i / 9, k = i % 9;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[((size_t)b * C + c) * 9 + k];
-    dw[k * C + c] = (float)s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};                                    // 4 independent chains keep the loads in flight; fixed combination order
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += part[((size_t)(b + j) * C + c) * 9 + k];
+    for (; b < nblocks; ++b) s[0] += part[((size_t)b * C + c) * 9 + k];
+    dw[k * C + c] = (float)((s[0] + s[1]) + (s[2] + s[3]));
 }
 
 // ---- stem: Conv2d(3, Cout, 3, stride 2, TF 'SAME'), image NCHW fp32, output gradient split16 [B][Ho][Wo][Cout] ----------------------------
@@ -192,9 +196,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_stage1(const float* __restrict
 __global__ __launch_bounds__(256) void stem_wgrad_stage2(const float* __restrict__ part, int nblocks, int nout, float* __restrict__ dw) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= nout) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)part[(size_t)b * nout + o];
-    dw[o] = (float)s;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += (double)part[(size_t)(b + j) * nout + o];
+    for (; b < nblocks; ++b) s[0] += (double)part[(size_t)b * nout + o];
+    dw[o] = (float)((s[0] + s[1]) + (s[2] + s[3]));
 }
 // data gradient: dImg[b,c,iy,ix] = sum_{ky,kx,co} dZ[b,oy,ox,co] * w[co][ky][kx][c]
 __global__ __launch_bounds__(256) void stem_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w /*[Cout][27]*/, float* __restrict__ dimg,

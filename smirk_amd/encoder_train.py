@@ -55,7 +55,7 @@ class _EncOps(_Ops):
 
 
 def _pw(conv):
-    """nn.Conv2d(cin, cout, 1) weight -> split16 [cout][cin]"""
+    """nn.Conv2d(cin, cout, 1) weight -> split16 [cout][cin]   (test helper; the step itself uses _EncOps.pack: both images in one launch)"""
     return _split16(conv.weight.detach().float().reshape(conv.out_channels, conv.in_channels).contiguous())
 
 
@@ -92,23 +92,29 @@ class BackboneTrainFunction(torch.autograd.Function):
         for stage in backbone.blocks:
             for blk in stage:
                 if blk.kind == "ds":
-                    z1 = ops.depthwise(x, _dw(blk.conv_dw), blk.stride)
+                    wdw = _dw(blk.conv_dw)
+                    z1 = ops.depthwise(x, wdw, blk.stride)
                     y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
-                    z2 = ops.pointwise(y1, _pw(blk.conv_pw), blk.conv_pw.out_channels)
+                    wf, wt = ops.pack(blk.conv_pw.weight)
+                    z2 = ops.pointwise(y1, wf, blk.conv_pw.out_channels)
                     out, m2, i2 = ops.bn_forward(z2, blk.bn2, False, residual=x if blk.skip else None)
-                    tape.append(("ds", blk, (x, z1, m1, i1, y1, z2, m2, i2)))
+                    tape.append(("ds", blk, (x, z1, m1, i1, y1, z2, m2, i2, wdw, wt)))
                 elif blk.kind == "ir":
-                    z1 = ops.pointwise(x, _pw(blk.conv_pw), blk.conv_pw.out_channels)
+                    wf1, wt1 = ops.pack(blk.conv_pw.weight)
+                    z1 = ops.pointwise(x, wf1, blk.conv_pw.out_channels)
                     y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
-                    z2 = ops.depthwise(y1, _dw(blk.conv_dw), blk.stride)
+                    wdw = _dw(blk.conv_dw)
+                    z2 = ops.depthwise(y1, wdw, blk.stride)
                     y2, m2, i2 = ops.bn_forward(z2, blk.bn2, True)
-                    z3 = ops.pointwise(y2, _pw(blk.conv_pwl), blk.conv_pwl.out_channels)
+                    wf3, wt3 = ops.pack(blk.conv_pwl.weight)
+                    z3 = ops.pointwise(y2, wf3, blk.conv_pwl.out_channels)
                     out, m3, i3 = ops.bn_forward(z3, blk.bn3, False, residual=x if blk.skip else None)
-                    tape.append(("ir", blk, (x, z1, m1, i1, y1, z2, m2, i2, y2, z3, m3, i3)))
+                    tape.append(("ir", blk, (x, z1, m1, i1, y1, z2, m2, i2, y2, z3, m3, i3, wt1, wdw, wt3)))
                 else:
-                    z1 = ops.pointwise(x, _pw(blk.conv), blk.conv.out_channels)
+                    wf, wt = ops.pack(blk.conv.weight)
+                    z1 = ops.pointwise(x, wf, blk.conv.out_channels)
                     out, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
-                    tape.append(("cn", blk, (x, z1, m1, i1)))
+                    tape.append(("cn", blk, (x, z1, m1, i1, wt)))
                 x = out
         Bf, hf, wf, Cf = x.shape
         hw_, hb = head.weight.detach().float().contiguous(), head.bias.detach().float().contiguous()
@@ -171,31 +177,31 @@ class BackboneTrainFunction(torch.autograd.Function):
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "cn":
-                _, blk, (x, z1, m1, i1) = rec
+                _, blk, (x, z1, m1, i1, wt) = rec
                 dz1 = bn_back(z1, g, blk.bn1, m1, i1, True)
                 pw_wgrad(blk.conv, dz1, x)
-                g = ops.pointwise(dz1, _pw_t(blk.conv), blk.conv.in_channels)
+                g = ops.pointwise(dz1, wt, blk.conv.in_channels)
             elif kind == "ir":
-                _, blk, (x, z1, m1, i1, y1, z2, m2, i2, y2, z3, m3, i3) = rec
+                _, blk, (x, z1, m1, i1, y1, z2, m2, i2, y2, z3, m3, i3, wt1, wdw, wt3) = rec
                 dz3 = bn_back(z3, g, blk.bn3, m3, i3, False)
                 pw_wgrad(blk.conv_pwl, dz3, y2)
-                dy2 = ops.pointwise(dz3, _pw_t(blk.conv_pwl), blk.conv_pwl.in_channels)
+                dy2 = ops.pointwise(dz3, wt3, blk.conv_pwl.in_channels)
                 dz2 = bn_back(z2, dy2, blk.bn2, m2, i2, True)
                 dw_wgrad(blk.conv_dw, dz2, y1, blk.stride)
                 b, h, w, c = y1.shape
-                dy1 = ops.depthwise_dgrad(dz2, _dw(blk.conv_dw), None, b, h, w, c, blk.stride)
+                dy1 = ops.depthwise_dgrad(dz2, wdw, None, b, h, w, c, blk.stride)
                 dz1 = bn_back(z1, dy1, blk.bn1, m1, i1, True)
                 pw_wgrad(blk.conv_pw, dz1, x)
-                g = ops.pointwise(dz1, _pw_t(blk.conv_pw), blk.conv_pw.in_channels, residual=g if blk.skip else None)
+                g = ops.pointwise(dz1, wt1, blk.conv_pw.in_channels, residual=g if blk.skip else None)
             elif kind == "ds":
-                _, blk, (x, z1, m1, i1, y1, z2, m2, i2) = rec
+                _, blk, (x, z1, m1, i1, y1, z2, m2, i2, wdw, wt) = rec
                 dz2 = bn_back(z2, g, blk.bn2, m2, i2, False)
                 pw_wgrad(blk.conv_pw, dz2, y1)
-                dy1 = ops.pointwise(dz2, _pw_t(blk.conv_pw), blk.conv_pw.in_channels)
+                dy1 = ops.pointwise(dz2, wt, blk.conv_pw.in_channels)
                 dz1 = bn_back(z1, dy1, blk.bn1, m1, i1, True)
                 dw_wgrad(blk.conv_dw, dz1, x, blk.stride)
                 b, h, w, c = x.shape
-                g = ops.depthwise_dgrad(dz1, _dw(blk.conv_dw), g if blk.skip else None, b, h, w, c, blk.stride)
+                g = ops.depthwise_dgrad(dz1, wdw, g if blk.skip else None, b, h, w, c, blk.stride)
             else:
                 _, (img, wst, z, mu, iv) = rec
                 dz = bn_back(z, g, backbone.bn1, mu, iv, True)

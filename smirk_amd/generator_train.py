@@ -60,6 +60,19 @@ class _Ops:
                                                 P(out), self.st))
         return out
 
+    def pack(self, weight, cin_off=0, cin=None, cin_pad=None, fwd=True, dgrad=True):
+        """nn.Conv2d weight (fp32 parameter) -> (forward weight split16 [Cout][T*cin_pad] or None, data-gradient weight split16 [cin_pad][T*Cout] or None)"""
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        cout, ctot, k = w.shape[0], w.shape[1], w.shape[2]
+        cin = ctot - cin_off if cin is None else cin
+        cp = cin if cin_pad is None else max(cin, cin_pad)
+        f = torch.empty(cout, k * k * cp, device=self.dev) if fwd else None
+        d = torch.empty(cp, k * k * cout, device=self.dev) if dgrad else None
+        L.check(self.lib.smirk_pack_conv_weights_split16(L.ptr(w), cout, ctot, cin_off, cin, k, cp, L.ptr(f, allow_none=True), L.ptr(d, allow_none=True), self.st))
+        return f, d
+
     def bn_forward(self, z, bn, relu, residual=None):
         C = z.shape[-1]
         M = z.numel() // C
@@ -126,11 +139,20 @@ class GeneratorTrainFunction(torch.autograd.Function):
         def block(seq, tag, x0, x1, h, w, c):
             m = dict(seq.named_children())
             c1, n1, c2, n2 = m[tag + "conv1"], m[tag + "norm1"], m[tag + "conv2"], m[tag + "norm2"]
-            z1 = ops.conv(x0, x1, _pack_fwd(c1.weight, 8 if x0.shape[-1] == 8 and c1.weight.shape[1] < 8 else None), B, h, w, c)
+            c0 = x0.shape[-1]
+            if x1 is None:
+                wf1, wd1a = ops.pack(c1.weight, cin_pad=c0)
+                wd1b = None
+            else:                                                          # decoder: forward weight over cat(up, skip), one data-gradient weight per source
+                wf1, _ = ops.pack(c1.weight, dgrad=False)
+                wd1a = ops.pack(c1.weight, 0, c0, fwd=False)[1]
+                wd1b = ops.pack(c1.weight, c0, x1.shape[-1], fwd=False)[1]
+            z1 = ops.conv(x0, x1, wf1, B, h, w, c)
             y1, mu1, iv1 = ops.bn_forward(z1, n1, True)
-            z2 = ops.conv(y1, None, _pack_fwd(c2.weight), B, h, w, c)
+            wf2, wd2 = ops.pack(c2.weight)
+            z2 = ops.conv(y1, None, wf2, B, h, w, c)
             y2, mu2, iv2 = ops.bn_forward(z2, n2, True)
-            tape.append(("block", (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2), (h, w, c)))
+            tape.append(("block", (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2, wd1a, wd1b, wd2), (h, w, c)))
             return y2
 
         def pool(t, h, w, c):
@@ -147,11 +169,13 @@ class GeneratorTrainFunction(torch.autograd.Function):
         b = block(module.bottleneck, "bottleneck", pool(e4, H // 8, W // 8, 8 * f), None, h16, w16, c16)
         for rb in module.resnet_blocks:
             cb = rb.conv_block
-            za = ops.conv(b, None, _pack_fwd(cb[1].weight), B, h16, w16, c16, reflect=True)
+            wfa, wda = ops.pack(cb[1].weight)
+            za = ops.conv(b, None, wfa, B, h16, w16, c16, reflect=True)
             ya, mua, iva = ops.bn_forward(za, cb[2], True)
-            zb = ops.conv(ya, None, _pack_fwd(cb[5].weight), B, h16, w16, c16, reflect=True)
+            wfb, wdb = ops.pack(cb[5].weight)
+            zb = ops.conv(ya, None, wfb, B, h16, w16, c16, reflect=True)
             nb, mub, ivb = ops.bn_forward(zb, cb[6], False, residual=b)
-            tape.append(("res", (cb[1], cb[2], cb[5], cb[6]), (b, za, mua, iva, ya, zb, mub, ivb), (h16, w16, c16)))
+            tape.append(("res", (cb[1], cb[2], cb[5], cb[6]), (b, za, mua, iva, ya, zb, mub, ivb, wda, wdb), (h16, w16, c16)))
             b = nb
         d = b
         for lvl, skip, div, c in ((4, e4, 16, 8 * f), (3, e3, 8, 4 * f), (2, e2, 4, 2 * f), (1, e1, 2, f)):
@@ -187,23 +211,22 @@ class GeneratorTrainFunction(torch.autograd.Function):
 
         def block_backward(rec, g):
             """g = dL/d(block output) -> (dL/d x0, dL/d x1 or None)"""
-            _, (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2), (h, w, c) = rec
+            _, (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2, wd1a, wd1b, wd2), (h, w, c) = rec
             dz2, dg2, db2 = ops.bn_backward(z2, g, n2, mu2, iv2, True)
             grads[id(n2.weight)], grads[id(n2.bias)] = dg2, db2
             grads[id(c2.weight)] = _to_conv_weight_grad(ops.wgrad(dz2, y1, B, h, w, c, c, 3), c, c)
-            dy1 = ops.conv(dz2, None, _pack_dgrad(c2.weight), B, h, w, c)
+            dy1 = ops.conv(dz2, None, wd2, B, h, w, c)
             dz1, dg1, db1 = ops.bn_backward(z1, dy1, n1, mu1, iv1, True)
             grads[id(n1.weight)], grads[id(n1.bias)] = dg1, db1
             c0 = x0.shape[-1]
             if x1 is None:
                 grads[id(c1.weight)] = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0, cin_real=c1.weight.shape[1])
-                return ops.conv(dz1, None, _pack_dgrad(c1.weight, c0), B, h, w, c0), None
+                return ops.conv(dz1, None, wd1a, B, h, w, c0), None
             cc1 = x1.shape[-1]
             gw0 = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0)
             gw1 = _to_conv_weight_grad(ops.wgrad(dz1, x1, B, h, w, c, cc1, 3), c, cc1)
             grads[id(c1.weight)] = torch.cat([gw0, gw1], 1)                # torch.cat((up, skip), 1): channels of source 0 first
-            wfull = c1.weight.detach()
-            return (ops.conv(dz1, None, _pack_dgrad(wfull[:, :c0]), B, h, w, c0), ops.conv(dz1, None, _pack_dgrad(wfull[:, c0:]), B, h, w, cc1))
+            return ops.conv(dz1, None, wd1a, B, h, w, c0), ops.conv(dz1, None, wd1b, B, h, w, cc1)
 
         g = dd
         skip_grad = {}
@@ -228,17 +251,17 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 wd = _split16(up.weight.detach().float().permute(0, 2, 3, 1).reshape(cin, 4 * cout).contiguous())
                 g = ops.conv(s2d, None, wd, B, h, w, cin, k=1)
             elif kind == "res":
-                _, (ca, na, cbv, nbv), (bin_, za, mua, iva, ya, zb, mub, ivb), (h, w, c) = rec
+                _, (ca, na, cbv, nbv), (bin_, za, mua, iva, ya, zb, mub, ivb, wda, wdb), (h, w, c) = rec
                 dzb, dgb, dbb = ops.bn_backward(zb, g, nbv, mub, ivb, False)
                 grads[id(nbv.weight)], grads[id(nbv.bias)] = dgb, dbb
                 grads[id(cbv.weight)] = _to_conv_weight_grad(ops.wgrad(dzb, ya, B, h, w, c, c, 3, reflect=True), c, c)
-                dpad = ops.conv(dzb, None, _pack_dgrad(cbv.weight), B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
+                dpad = ops.conv(dzb, None, wdb, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 dya = torch.empty_like(ya)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), None, L.ptr(dya), B, h, w, c, st))
                 dza, dga, dba = ops.bn_backward(za, dya, na, mua, iva, True)
                 grads[id(na.weight)], grads[id(na.bias)] = dga, dba
                 grads[id(ca.weight)] = _to_conv_weight_grad(ops.wgrad(dza, bin_, B, h, w, c, c, 3, reflect=True), c, c)
-                dpad = ops.conv(dza, None, _pack_dgrad(ca.weight), B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
+                dpad = ops.conv(dza, None, wda, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 gin = torch.empty_like(bin_)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), L.ptr(g), L.ptr(gin), B, h, w, c, st))     # + the identity branch
                 g = gin
