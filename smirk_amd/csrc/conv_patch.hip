@@ -72,10 +72,19 @@ struct PatchArgs {
     const float *fw, *fb;
     float* fout;
     int fcout;
+    long long* dbg;  // optional phase time stamps (s_memtime) of wave 0 of a few workgroups: [block][item][5]; tools/patch_timeline.py
     int use_buf;     // operand DMA through buffer resources (32-bit per-lane offsets, OOB rows for the zero padding): C0, C1 powers of two, tensors < 2 GiB
 };
 
 __device__ __forceinline__ int lds_piece_p(int row, int piece) { return row * 32 + ((piece ^ ((row >> 1) & 7)) << 2); }
+
+// "The fragments of this step have arrived": an empty asm that READS them.  The compiler's waitcnt pass then places its wait here, i.e. BEFORE the next
+// step's reads are issued, where `lgkmcnt(0)` is exact (only this step's reads are outstanding) — placed in front of the first MFMA instead, it emitted
+// `lgkmcnt(0)` for every second step although the six newest reads belonged to the following step (ISA of the 18-step loop), exposing the LDS latency.
+__device__ __forceinline__ void frag_ready(const half8& a0, const half8& a1, const half8& a2, const half8& a3, const half8& b0, const half8& b1,
+                                           const half8& b2, const half8& b3) {
+    asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
 
 __device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
 #pragma unroll
@@ -88,26 +97,52 @@ __device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
 
 // NST = number of input stages: 2 = next halo patch DMA'd under the current MFMAs (one workgroup per CU when the weights are large);
 // 1 = single stage, used when weights + one stage fit twice into a CU's 160 KiB: TWO workgroups per CU then cover each other's DMA
-// wait / epilogue, which hides more latency than double buffering a lone 4-wave workgroup.
-template <int TN, int NST>
-__global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(PatchArgs a) {
+// wait / epilogue, which hides more latency than double buffering a lone 4-wave workgroup;
+// 3 = RING of three stages with 16 x 8-pixel patches (PTH = 8, 23 KiB per stage): the DMA of item n+2 is issued when item n starts, so ~2 stages
+// (47 KB) per CU are in flight at all times — the PMC profile of the 1- / 2-stage forms (profiles/r02_pmc_patch11.txt) shows the waves parked on
+// `s_waitcnt vmcnt` / the barrier 58 % of their life with MFMA and LDS each ~27 % busy: HBM latency, not bandwidth.  The wait at the top of item n is
+// COUNTED (the DMA of item n+1 may stay outstanding): loads return in order among loads, so "at most nq outstanding" proves item n has landed; stores of
+// earlier epilogues can only make the wait stricter.
+// GROUPS = 2: one 512-thread workgroup = two independent 4-wave pipelines (each its own patches, stages and barriers) sharing ONE copy of the weights
+// in LDS — what two workgroups per CU do, minus the second 36-72 KiB weight image, which is what makes room for double-buffered stages.  The groups
+// synchronise among their own four waves through an LDS arrival counter (gfx950 has one hardware barrier per workgroup and no named barriers).
+__device__ __forceinline__ void group_barrier(unsigned* cnt, unsigned& epoch, int lane) {
+    epoch += 4;
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+template <int TN, int NST, int PTH, int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) void conv3x3_patch_kernel(PatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COUT = TN * 32;
     constexpr int EPI_LD = COUT + 4;
-    static_assert(4 * 32 * EPI_LD <= PSTAGE, "transpose buffers must fit in one input stage");
-    float* Wl = smem;                                            // [nchunk][9][COUT][32]
-    float* St = smem + a.nchunk * 9 * COUT * 32;                 // NST input stages
+    constexpr int PHR = PTH + 2;                                  // halo rows
+    constexpr int PPIXT = PHR * PH;                               // halo pixels
+    constexpr int PSTG = ((PPIXT + 7) / 8 * 8) * 32;              // dwords per input stage
+    constexpr int MT = PTH / 8;                                   // 32-pixel M tiles (2 rows of 16) per wave
+    constexpr int WROWS = PTH / 4;                                // output rows per wave
+    static_assert(4 * 32 * EPI_LD <= PSTG, "transpose buffers must fit in one input stage");
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, group = GROUPS == 1 ? 0 : wave_all >> 2, wave = GROUPS == 1 ? wave_all : wave_all & 3;
+    unsigned* gcnt = (unsigned*)smem + group * 32;               // GROUPS == 2: arrival counters live in the first 256 bytes
+    float* Wl = smem + (GROUPS == 2 ? 64 : 0);                   // [nchunk][9][COUT][32]
+    float* St = Wl + a.nchunk * 9 * COUT * 32 + group * NST * PSTG;     // this group's NST input stages
+    unsigned epoch = 0;
+    if (GROUPS == 2 && tid < 64) ((unsigned*)smem)[tid] = 0u;
+    auto gbar = [&]() {
+        if (GROUPS == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        else group_barrier(gcnt, epoch, lane);
+    };
     const int fr = lane & 31, hb = lane >> 5;
     const int Cin = a.C0 + a.C1, K = 9 * Cin;
 
     // ---- weights -> LDS once: row (cc, tap, n) = 128 bytes at w[n][tap*Cin + cc*32 ...]; pieces beyond the layer's channels are zero
     {
         const int rows = a.nchunk * 9 * COUT;
-        for (int r0 = wave * 8; r0 < rows; r0 += 32) {
+        for (int r0 = wave_all * 8; r0 < rows; r0 += 32 * GROUPS) {
             const int row = r0 + (lane >> 3), pos = lane & 7;
             const int piece = pos ^ ((row >> 1) & 7);
             const int cc = row / (9 * COUT), rem = row - cc * 9 * COUT, tap = rem / COUT, n = rem - tap * COUT;
@@ -116,23 +151,26 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + r0 * 32), 16, 0, 0);
         }
     }
-    // ---- per-lane halo pixel slots: instruction q of this wave covers halo pixels (q*4 + wave)*8 .. +7
-    constexpr int NQ = (PPIX + 31) / 32;                         // 11 (the last one is partial)
-    int hp_y[NQ], hp_x[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int pix = (q * 4 + wave) * 8 + (lane >> 3);
-        hp_y[q] = pix < PPIX ? pix / PH : -100000;
-        hp_x[q] = pix - (pix / PH) * PH;
-    }
-    const int tiles_x = a.W / PT, tiles_per_img = (a.H / PT) * tiles_x;
+    // ---- per-lane halo pixel slots: instruction q of this wave covers halo pixels (q*4 + wave)*8 .. +7.  The slot's (row, column) is recomputed at every
+    // issue (a multiply-shift division by 18) instead of being kept in 2 x 11 registers: with them the 2-workgroups-per-CU variant spilled, and the
+    // scratch reloads in front of each DMA instruction made ISSUING one halo patch cost 14k cycles — 58 % of a patch's period (tools/patch_timeline.py)
+    constexpr int NQ = (PPIXT + 31) / 32;
+    auto hp = [&](int q, int& pix, int& y, int& x) {
+        int l8 = lane >> 3;
+        asm volatile("" : "+v"(l8));                              // opaque per call: nothing derived from the slot may be hoisted out of the patch loop
+        pix = (q * 4 + wave) * 8 + l8;
+        const int yy = (pix * 3641) >> 16;                        // pix / 18 for pix < 400
+        y = pix < PPIXT ? yy : -100000;                           // slots past the halo: row far outside any image -> zero fill
+        x = pix - yy * PH;
+    };
+    const int tiles_x = a.W / PT, tiles_per_img = (a.H / PTH) * tiles_x;
     const int nitem = a.npatch * a.nchunk;
     auto item_patch = [&](int item, int& b, int& oy0, int& ox0, int& cc) {
         const int p = item / a.nchunk;
         cc = item - p * a.nchunk;
         b = p / tiles_per_img;
         const int t = p - b * tiles_per_img;
-        oy0 = (t / tiles_x) * PT;
+        oy0 = (t / tiles_x) * PTH;
         ox0 = (t - (t / tiles_x) * tiles_x) * PT;
     };
     PATCH_BUF_DECL()
@@ -143,16 +181,18 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
         const bool s1 = c0 >= a.C0;
         const float* src = s1 ? a.in1 : a.in0;
         const int cs = s1 ? a.C1 : a.C0, cb = s1 ? c0 - a.C0 : c0;
-        float* dst = St + st * PSTAGE;
+        float* dst = St + st * PSTG;
         if (a.use_buf) {
             const int basepix = (b * a.H + oy0 - 1) * a.W + ox0 - 1, sh = s1 ? bsh1 : bsh0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if ((q * 4 + swave) * 8 < PPIX) {
-                    const int pix = (q * 4 + wave) * 8 + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
-                    const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                if ((q * 4 + swave) * 8 < PPIXT) {
+                    int pix, hy, hx;
+                    hp(q, pix, hy, hx);
+                    const int piece = (lane & 7) ^ ((pix >> 1) & 7);
+                    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                     const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (cb + piece * 4) < cs;
-                    const unsigned vo = ok ? ((unsigned)(basepix + hp_y[q] * a.W + hp_x[q]) << sh) + (unsigned)piece * 16u : 0x80000000u;
+                    const unsigned vo = ok ? ((unsigned)(basepix + hy * a.W + hx) << sh) + (unsigned)piece * 16u : 0x80000000u;
                     PATCH_BUF_LOAD(s1, dst + (q * 4 + swave) * 8 * 32, vo, cb * 4);
                 }
             }
@@ -161,9 +201,11 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int pixbase = (q * 4 + wave) * 8;
-            if (pixbase < PPIX) {                                // wave-uniform
-                const int pix = pixbase + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
-                const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+            if (pixbase < PPIXT) {                               // wave-uniform
+                int pix, hy, hx;
+                hp(q, pix, hy, hx);
+                const int piece = (lane & 7) ^ ((pix >> 1) & 7);
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                 const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (cb + piece * 4) < cs;
                 const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);     // keep the unselected address in range
                 const float* g = psel_p(ok, src + ((size_t)(b * a.H + cy) * a.W + cx) * cs + cb + piece * 4, g_zero16);
@@ -172,41 +214,70 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
         }
     };
 
-    f32x16 acc0[2][TN], acc1[2][TN];
+    f32x16 acc0[MT][TN], acc1[MT][TN];
+    // epilogue coefficients of THIS lane's channel group (g = lane % (COUT/8) for every item of every tile): loaded once, not once per tile — inside
+    // the persistent loop each reload was a global-load round trip in front of the stores
+    float ep_sc[8], ep_sh[8];
+    {
+        const int g = lane % (COUT / 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { ep_sc[q] = a.scale ? a.scale[g * 8 + q] : 1.f; ep_sh[q] = a.shift ? a.shift[g * 8 + q] : 0.f; }
+    }
     const int ry = fr >> 4, rx = fr & 15;
-    int item = blockIdx.x * a.nchunk;                            // each block walks whole patches: items blockIdx*nchunk .. , stride grid*nchunk
-    const int stride = gridDim.x * a.nchunk;
+    int item = (blockIdx.x * GROUPS + group) * a.nchunk;         // each 4-wave pipeline walks whole patches
+    const int stride = gridDim.x * GROUPS * a.nchunk;
+    if (GROUPS == 2) __syncthreads();                            // the zeroed counters are visible before any arrival
     auto next_item = [&](int it) { return (it % a.nchunk == a.nchunk - 1) ? it - (a.nchunk - 1) + stride : it + 1; };
     if (item < nitem) issue_item(item, 0);
-    int st = 0;
+    if (NST == 3 && item < nitem && next_item(item) < nitem) issue_item(next_item(item), 1);
+    // DMA instructions one item costs THIS wave (the ring's counted wait): q with (4 q + wave) * 8 < PPIXT
+    int nq_w = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) nq_w += ((q * 4 + swave) * 8 < PPIXT) ? 1 : 0;
+    int st = 0, dbg_n = 0;
+    bool first = true;
+    if (GROUPS == 2 && !(item < nitem)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // idle group: still owes its weight share + the barrier
     while (item < nitem) {
         int b, oy0, ox0, cc;
         item_patch(item, b, oy0, ox0, cc);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + this wave's LDS reads of the stage about to be refilled
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                           // s_barrier is IntrNoMem: stop the compiler moving LDS reads above it
-        // stage st (and, first time, the weights) has landed
         const int nxt = next_item(item);
+        const bool stamp = a.dbg && wave_all == 0 && lane == 0 && (blockIdx.x & 63) == 0 && dbg_n < 48;
+        long long* dbgp = stamp ? a.dbg + ((size_t)(blockIdx.x >> 6) * 48 + dbg_n) * 6 : nullptr;
+        if (stamp) { dbgp[0] = __builtin_amdgcn_s_memtime(); ++dbg_n; }
+        if (NST == 3 && nxt < nitem) {                            // item + 1 may stay in flight
+            if (nq_w == NQ) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NQ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NQ - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + this wave's LDS reads of the stage about to be refilled
+        }
+        if (GROUPS == 2 && first) { __syncthreads(); first = false; }   // the OTHER group's share of the weight DMA has landed too
+        else gbar();
+        // stage st (and, first time, the weights) has landed
+        if (stamp) dbgp[1] = __builtin_amdgcn_s_memtime();
         if (NST == 2 && nxt < nitem) issue_item(nxt, st ^ 1);    // the other stage is free: refill it under the MFMAs
+        if (NST == 3 && nxt < nitem) {
+            const int nn = next_item(nxt);
+            if (nn < nitem) issue_item(nn, st == 0 ? 2 : st - 1);     // (st + 2) % 3: the stage item - 1 has just left
+        }
         if (cc == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
         }
-        const float* A = St + st * PSTAGE;
+        const float* A = St + st * PSTG;
         const float* Wc = Wl + cc * 9 * COUT * 32;
         // 18 (tap, 16-k step) stages, software-pipelined in registers: the LDS reads of stage t+1 are issued before the MFMAs of stage t
         {
-            half8 ah[2][2], al[2][2], bh[2][TN], bl[2][TN];
+            half8 ah[2][MT], al[2][MT], bh[2][TN], bl[2][TN];
             auto fetch = [&](int t, int set) {
                 const int tap = t >> 1, sstep = t & 1, ky = tap / 3, kx = tap % 3;
                 const int pc = 2 * (2 * sstep + hb);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pix = (4 * wave + 2 * i + ry + ky) * PH + rx + kx;
+                for (int i = 0; i < MT; ++i) {
+                    const int pix = (WROWS * wave + 2 * i + ry + ky) * PH + rx + kx;
                     ah[set][i] = *(const half8*)(A + lds_piece_p(pix, pc));
                     al[set][i] = *(const half8*)(A + lds_piece_p(pix, pc + 1));
                 }
@@ -221,28 +292,33 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
 #pragma unroll
             for (int t = 0; t < 18; ++t) {
                 const int cur = t & 1;
-                if (t + 1 < 18) fetch(t + 1, cur ^ 1);
+                frag_ready(ah[cur][0], al[cur][0], ah[cur][MT - 1], al[cur][MT - 1], bh[cur][0], bl[cur][0], bh[cur][TN - 1], bl[cur][TN - 1]);
+                if (t + 1 < 18) fetch(t + 1, cur ^ 1);           // in flight under this step's 3 * MT * TN MFMAs
+                __builtin_amdgcn_sched_barrier(0);               // keep it that way: the machine scheduler otherwise sinks each read next to its MFMA
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur][j], acc0[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur][j], acc1[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur][j], acc1[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);               // the next step's reads stay behind this step's MFMAs in program order
             }
         }
+        if (stamp) dbgp[2] = __builtin_amdgcn_s_memtime();
         if (cc == a.nchunk - 1) {
             // ---- epilogue: this stage's LDS is dead now (next DMA went to the other stage): use it as per-wave transpose buffers
-            lds_barrier();
-            float* ebuf = St + st * PSTAGE + wave * 32 * EPI_LD;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gbar();
+            float* ebuf = St + st * PSTG + wave * 32 * EPI_LD;
             constexpr int GPR = COUT / 8, ITEMS = 32 * GPR / 64;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -252,19 +328,17 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
 #pragma unroll
                 for (int it = 0; it < ITEMS; ++it) {
                     const int e = it * 64 + lane, row = e / GPR, g = e % GPR;
-                    const int oy = oy0 + 4 * wave + 2 * i + (row >> 4), ox = ox0 + (row & 15);
+                    const int oy = oy0 + WROWS * wave + 2 * i + (row >> 4), ox = ox0 + (row & 15);
                     float v[8];
                     *(f32x4*)v = *(const f32x4*)(ebuf + row * EPI_LD + g * 8);
                     *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * EPI_LD + g * 8 + 4);
                     if (a.scale) {
-                        const f32x4 s0 = *(const f32x4*)(a.scale + g * 8), s1 = *(const f32x4*)(a.scale + g * 8 + 4);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+                        for (int q = 0; q < 8; ++q) v[q] *= ep_sc[q];
                     }
                     if (a.shift) {
-                        const f32x4 s0 = *(const f32x4*)(a.shift + g * 8), s1 = *(const f32x4*)(a.shift + g * 8 + 4);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
+                        for (int q = 0; q < 8; ++q) v[q] += ep_sh[q];
                     }
                     if (a.act == SMIRK_ACT_RELU) {
 #pragma unroll
@@ -302,11 +376,17 @@ __global__ __launch_bounds__(256, NST == 1 ? 2 : 1) void conv3x3_patch_kernel(Pa
                 wave_lds_fence();          // per-wave transpose buffer: LDS ops of one wave execute in order
             }
         }
+        if (stamp) dbgp[3] = __builtin_amdgcn_s_memtime();
         if (NST == 1) {
-            lds_barrier();                                        // everyone is done with the only stage (compute or epilogue)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gbar();                                               // everyone is done with the only stage (compute or epilogue)
+            if (stamp) dbgp[4] = __builtin_amdgcn_s_memtime();
             if (nxt < nitem) issue_item(nxt, 0);
-        } else {
+            if (stamp) dbgp[5] = __builtin_amdgcn_s_memtime();
+        } else if (NST == 2) {
             st ^= 1;
+        } else {
+            st = st == 2 ? 0 : st + 1;
         }
         item = nxt;
     }
@@ -331,13 +411,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
     const int Cin = a.C0 + a.C1, K = 9 * Cin;
 
     constexpr int NQ = (PPIX + 31) / 32;
-    int hp_y[NQ], hp_x[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int pix = (q * 4 + wave) * 8 + (lane >> 3);
-        hp_y[q] = pix < PPIX ? pix / PH : -100000;
-        hp_x[q] = pix - (pix / PH) * PH;
-    }
+    auto hp = [&](int q, int& pix, int& y, int& x) {              // halo slot -> (row, column), recomputed per issue (see conv3x3_patch_kernel)
+        int l8 = lane >> 3;
+        asm volatile("" : "+v"(l8));
+        pix = (q * 4 + wave) * 8 + l8;
+        const int yy = (pix * 3641) >> 16;
+        y = pix < PPIX ? yy : -100000;
+        x = pix - yy * PH;
+    };
     const int tiles_x = a.W / PT, tiles_per_img = (a.H / PT) * tiles_x;
     auto patch_origin = [&](int p, int& b, int& oy0, int& ox0) {
         b = p / tiles_per_img;
@@ -360,9 +441,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
             for (int q = 0; q < NQ; ++q) {
                 if ((q * 4 + swave) * 8 < PPIX) {
                     const int pix = (q * 4 + wave) * 8 + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
-                    const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                    int pix_, hy, hx;
+                    hp(q, pix_, hy, hx);
+                    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                     const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                    const unsigned vo = ok ? ((unsigned)(basepix + hp_y[q] * a.W + hp_x[q]) << sh) + (unsigned)piece * 16u : 0x80000000u;
+                    const unsigned vo = ok ? ((unsigned)(basepix + hy * a.W + hx) << sh) + (unsigned)piece * 16u : 0x80000000u;
                     PATCH_BUF_LOAD(s1, dst + (q * 4 + swave) * 8 * 32, vo, cb * 4);
                 }
             }
@@ -373,7 +456,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
             const int pixbase = (q * 4 + wave) * 8;
             if (pixbase < PPIX) {
                 const int pix = pixbase + (lane >> 3), piece = (lane & 7) ^ ((pix >> 1) & 7);
-                const int iy = oy0 - 1 + hp_y[q], ix = ox0 - 1 + hp_x[q];
+                int pix_, hy, hx;
+                hp(q, pix_, hy, hx);
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                 const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);     // keep the unselected address in range
                 const float* g = psel_p(ok, src + ((size_t)(b * a.H + cy) * a.W + cx) * cs + cb + piece * 4, g_zero16);
@@ -391,6 +476,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
     };
 
     f32x16 acc0[2][2], acc1[2][2];                               // [half][M-tile]
+    float ep_sc[8], ep_sh[8];                                    // this lane's epilogue coefficients (g = lane % 8), loaded once
+    {
+        const int g = lane % (COUT / 8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { ep_sc[q] = a.scale ? a.scale[g * 8 + q] : 1.f; ep_sh[q] = a.shift ? a.shift[g * 8 + q] : 0.f; }
+    }
     const int ry = fr >> 4, rx = fr & 15;
     // 18 (tap, 16-k step) stages, software-pipelined in registers: the LDS reads of stage t+1 are issued before the MFMAs of stage t
     auto run = [&](const float* A, const float* Wc, f32x16 (&c0)[2], f32x16 (&c1)[2]) {
@@ -412,7 +503,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
 #pragma unroll
         for (int t = 0; t < 18; ++t) {
             const int cur = t & 1;
+            frag_ready(ah[cur][0], al[cur][0], ah[cur][1], al[cur][1], bh[cur], bl[cur], bh[cur], bl[cur]);
             if (t + 1 < 18) fetch(t + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) c0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], c0[i], 0, 0, 0);
 #pragma unroll
@@ -473,14 +566,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
                     *(f32x4*)v = *(const f32x4*)(ebuf + row * EPI_LD + g * 8);
                     *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * EPI_LD + g * 8 + 4);
                     if (a.scale) {
-                        const f32x4 s0 = *(const f32x4*)(a.scale + g * 8), s1 = *(const f32x4*)(a.scale + g * 8 + 4);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+                        for (int q = 0; q < 8; ++q) v[q] *= ep_sc[q];
                     }
                     if (a.shift) {
-                        const f32x4 s0 = *(const f32x4*)(a.shift + g * 8), s1 = *(const f32x4*)(a.shift + g * 8 + 4);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
+                        for (int q = 0; q < 8; ++q) v[q] += ep_sh[q];
                     }
                     if (a.act == SMIRK_ACT_RELU) {
 #pragma unroll
@@ -525,6 +616,10 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
                                int fcout) {
     PatchArgs a;
     a.fw = fw; a.fb = fb; a.fout = fout; a.fcout = fcout;
+    {   // debugging aid: SMIRK_PATCH_DBG=<device address (hex) of a zeroed int64 buffer of >= 8*48*6 entries>, see tools/patch_timeline.py
+        const char* e = getenv("SMIRK_PATCH_DBG");
+        a.dbg = e ? (long long*)strtoull(e, nullptr, 16) : nullptr;
+    }
     a.in0 = (const float*)in0; a.in1 = (const float*)in1; a.w = (const float*)w; a.scale = scale; a.shift = shift; a.out = (float*)out;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
     a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
@@ -549,20 +644,52 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
         return smirk_launch_status();
     }
     const size_t wbytes = (size_t)a.nchunk * 9 * d->Cout * 32 * 4;
-    const bool one_stage = (wbytes + (size_t)PSTAGE * 4) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
-    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4;
-    const int cap = one_stage ? 512 : 256;
-    const int grid = a.npatch < cap ? a.npatch : cap;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 3, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 3, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (d->Cout == 32 && one_stage) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1>), dim3(grid), dim3(256), lds, st, a);
-    else if (d->Cout == 32) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2>), dim3(grid), dim3(256), lds, st, a);
-    else SMIRK_LAUNCH((conv3x3_patch_kernel<2, 2>), dim3(grid), dim3(256), lds, st, a);
+    // three-stage ring variants (Cout = 32), opt-in for A/B: SMIRK_PATCH_RING=8 (16 x 8 patches) / =16 (16 x 16 patches, single-chunk layers only).
+    // Measured (B = 128, 224^2, 32 -> 32): ring of 16 x 8 patches 0.84 ms vs 0.54 ms for two single-stage workgroups per CU — a lone 4-wave
+    // workgroup with ONE M tile per wave has two accumulator chains per wave and nothing else on its SIMD: MFMA latency, not DMA latency, decides.
+    constexpr size_t PSTG8 = (size_t)(((8 + 2) * PH + 7) / 8 * 8) * 32 * 4;
+    const char* ring_env = getenv("SMIRK_PATCH_RING");
+    const int ring = ring_env ? atoi(ring_env) : 0;
+    if (ring == 8 && d->Cout == 32 && d->H % 8 == 0 && wbytes + 3 * PSTG8 <= 160 * 1024) {
+        a.npatch = d->B * (d->H / 8) * (d->W / PT);
+        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 3, 8, 1>), dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), wbytes + 3 * PSTG8, st, a);
+        return smirk_launch_status();
+    }
+    if (ring == 28 && d->Cout == 32 && d->H % 8 == 0 && 256 + wbytes + 4 * PSTG8 <= 160 * 1024) {          // two groups x two stages of 16 x 8 patches
+        a.npatch = d->B * (d->H / 8) * (d->W / PT);
+        const int g2 = (a.npatch + 1) / 2;
+        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2, 8, 2>), dim3(g2 < 256 ? g2 : 256), dim3(512), 256 + wbytes + 4 * PSTG8, st, a);
+        return smirk_launch_status();
+    }
+    if ((ring == 28 || ring == 18) && d->Cout == 32 && d->H % 8 == 0 && 256 + wbytes + 2 * PSTG8 <= 160 * 1024) {   // two groups x one stage (two-chunk layers)
+        a.npatch = d->B * (d->H / 8) * (d->W / PT);
+        const int g2 = (a.npatch + 1) / 2;
+        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1, 8, 2>), dim3(g2 < 256 ? g2 : 256), dim3(512), 256 + wbytes + 2 * PSTG8, st, a);
+        return smirk_launch_status();
+    }
+    if (ring == 16 && d->Cout == 32 && wbytes + 3 * (size_t)PSTAGE * 4 <= 160 * 1024) {
+        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 3, 16, 1>), dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), wbytes + 3 * (size_t)PSTAGE * 4, st, a);
+        return smirk_launch_status();
+    }
+    const bool one_stage = (wbytes + (size_t)PSTAGE * 4) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
+    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4;
+    static const char* cap_env = getenv("SMIRK_PATCH_CAP");
+    const int cap = cap_env ? atoi(cap_env) : (one_stage ? 512 : 256);
+    const int grid = a.npatch < cap ? a.npatch : cap;
+    if (d->Cout == 32 && one_stage) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1, 16, 1>), dim3(grid), dim3(256), lds, st, a);
+    else if (d->Cout == 32) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2, 16, 1>), dim3(grid), dim3(256), lds, st, a);
+    else SMIRK_LAUNCH((conv3x3_patch_kernel<2, 2, 16, 1>), dim3(grid), dim3(256), lds, st, a);
     return smirk_launch_status();
 }
 

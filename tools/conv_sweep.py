@@ -51,6 +51,7 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--only", default="", help="substring filter on the layer name")
     ap.add_argument("--ab-pp", action="store_true", help="time every layer twice: SMIRK_IGEMM_PP=0 (128x128 kernel) and default (ping-pong kernel where eligible)")
+    ap.add_argument("--ab-env", default="", help="NAME=VALUE: time every layer twice, with this environment variable set and without")
     a = ap.parse_args()
     B = a.batch
     layers = [  # name, H, C0, C1, Cout, k, convt, reflect, count in the generator
@@ -72,6 +73,12 @@ if __name__ == "__main__":
             ms0, tf0 = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
             del os.environ["SMIRK_IGEMM_PP"]
             extra = f"   [PP off: {ms0:8.3f} ms {tf0:7.1f} TFLOP/s]"
+        if a.ab_env:
+            k_, v_ = a.ab_env.split("=", 1)
+            os.environ[k_] = v_
+            ms0, tf0 = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
+            del os.environ[k_]
+            extra = f"   [{a.ab_env}: {ms0:8.3f} ms {tf0:7.1f} TFLOP/s]"
         ms, tf = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
         tot_ms += ms * cnt; tot_fl += tf * ms * cnt
         print(f"{name:14s} H={H:3d} Cin={C0 + C1:4d} Cout={Cout:4d} k={k} convT={convt} x{cnt:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s{extra}", flush=True)
