@@ -14,11 +14,14 @@
 //                      (925 MB at B=256 in the reference) + add_directionlight (renderer.py:239-250).
 //
 // Bound: HBM/L2 (integer + fp32 scan work).  Algorithmic bytes per face (image): verts in 60 KB, image out 602 KB.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define TILE_W 32
 #define TILE_H 8
 #define FACE_CHUNK 64
+#define FACE_REC 20               // floats per staged face record in raster_tile
 #define K_EPS 1e-8f
 
 struct MeshDev {
@@ -137,11 +140,11 @@ __global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H
 __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int W, const float* __restrict__ frec,
                                                    const short4* __restrict__ fbox, const float* __restrict__ normals,
                                                    float* __restrict__ img, long long* __restrict__ p2f_out,
-                                                   float* __restrict__ bary_out, float* __restrict__ zbuf_out) {
+                                                   float* __restrict__ bary_out, float* __restrict__ zbuf_out, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    // layout: [FACE_CHUNK*9 floats][FACE_CHUNK ints][1 int counter (+3 pad)][Ff uint16 list]
+    // layout: [FACE_CHUNK*FACE_REC floats][FACE_CHUNK ints][1 int counter (+3 pad)][Ff uint16 list]
     float* sface = (float*)dyn_smem;
-    int* sfid = (int*)(sface + FACE_CHUNK * 9);
+    int* sfid = (int*)(sface + FACE_CHUNK * FACE_REC);
     int* scount = sfid + FACE_CHUNK;
     unsigned short* slist = (unsigned short*)(scount + 4);
 
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
     if (tid == 0) *scount = 0;
     __syncthreads();
     const short4* boxes = fbox + (size_t)b * m.Ff;
-    for (int f = tid; f < m.Ff; f += 256) {
+    for (int f = tid; f < ((ablate & 2) ? 0 : m.Ff); f += 256) {          // ablate: timing experiments only ($SMIRK_RASTER_ABLATE)
         const short4 bx = boxes[f];
         if (bx.x <= tx1 && bx.y >= tx0 && bx.z <= ty1 && bx.w >= ty0 && bx.x <= bx.y) {
             const int slot = atomicAdd(scount, 1);
@@ -161,31 +164,67 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         }
     }
     __syncthreads();
-    const int n = *scount;
+    const int n = (ablate & 1) ? 0 : *scount;
 
-    const int xi = tx0 + (tid & (TILE_W - 1)), yi = ty0 + (tid / TILE_W);
+    // a wave owns an 8 x 8 pixel block of the 32 x 8 tile (not a 32 x 2 strip): with face boxes of ~20 px the block is touched by 1.5x fewer faces
+    const int xi = tx0 + (tid >> 6) * 8 + (tid & 7), yi = ty0 + ((tid & 63) >> 3);
     const bool live = (xi < W) && (yi < H);
     const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
     float best_z = 0.f, bw0 = -1.f, bw1 = -1.f, bw2 = -1.f;
     int best_f = -1;
     const float* fr = frec + (size_t)b * m.Ff * 9;
+    // NDC box of this wave's 8 x 8 block (NDC decreases with the pixel index): the same pix_to_ndc values its lanes use
+    const int lane = tid & 63, wx0 = tx0 + (tid >> 6) * 8;
+    const float sx_hi = pix_to_ndc(W - 1 - wx0, W), sx_lo = pix_to_ndc(W - 1 - (wx0 + 7), W);
+    const float sy_hi = pix_to_ndc(H - 1 - ty0, H), sy_lo = pix_to_ndc(H - 1 - (ty0 + TILE_H - 1), H);
     for (int base = 0; base < n; base += FACE_CHUNK) {
         const int cnt = min(FACE_CHUNK, n - base);
         __syncthreads();
-        for (int i = tid; i < cnt * 9; i += 256) sface[i] = fr[(size_t)slist[base + i / 9] * 9 + (i % 9)];
-        if (tid < cnt) sfid[tid] = slist[base + tid];
+        // stage one record per face: everything that does not depend on the pixel is computed ONCE here, with the same operations (and
+        // -ffp-contract=off) the per-pixel code used, so every value is bit-identical: vertices, area + eps, the face's NDC box and the
+        // (b - a) factors of the three edge functions
+        if (tid < cnt) {
+            const int f = slist[base + tid];
+            const float* g = fr + (size_t)f * 9;
+            const float x0 = g[0], y0 = g[1], z0 = g[2], x1 = g[3], y1 = g[4], z1 = g[5], x2 = g[6], y2 = g[7], z2 = g[8];
+            float* r = sface + tid * FACE_REC;
+            r[0] = x0; r[1] = y0; r[2] = z0; r[3] = x1; r[4] = y1; r[5] = z1; r[6] = x2; r[7] = y2; r[8] = z2;
+            r[9] = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+            r[10] = fminf(x0, fminf(x1, x2)); r[11] = fmaxf(x0, fmaxf(x1, x2));
+            r[12] = fminf(y0, fminf(y1, y2)); r[13] = fmaxf(y0, fmaxf(y1, y2));
+            r[14] = y2 - y1; r[15] = x2 - x1;                    // w0: edge_fn(p, v1, v2)
+            r[16] = y0 - y2; r[17] = x0 - x2;                    // w1: edge_fn(p, v2, v0)
+            r[18] = y1 - y0; r[19] = x1 - x0;                    // w2: edge_fn(p, v0, v1)
+            sfid[tid] = f;
+        }
         __syncthreads();
-        for (int j = 0; j < cnt; ++j) {
-            const float* v = sface + j * 9;
-            const float x0 = v[0], y0 = v[1], z0 = v[2], x1 = v[3], y1 = v[4], z1 = v[5], x2 = v[6], y2 = v[7], z2 = v[8];
-            const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
-            const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
-            if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
-            const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
-            const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
-            const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
-            const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
-            const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+        // wave-level cull: a wave owns an 8 x 8 pixel block; lane l tests face l of the chunk against the block's NDC box (64 faces in parallel,
+        // one LDS read each) and only the faces that can touch the strip are walked.  Conservative w.r.t. the per-pixel box test below (a face
+        // whose box misses the strip fails that test at every pixel of it), so the result is unchanged; it removes the serial
+        // read-compare-branch per face and pixel that made this loop 90 % of the kernel (tools/raster_time.py).
+        bool rel = false;
+        if (lane < cnt) {
+            const float* r = sface + lane * FACE_REC;
+            rel = !(sx_lo > r[11] || sx_hi < r[10] || sy_lo > r[13] || sy_hi < r[12]);
+        }
+        unsigned long long relmask = __ballot(rel);
+        while (relmask) {
+            const int j = __builtin_ctzll(relmask);
+            relmask &= relmask - 1;
+            const float* v = sface + j * FACE_REC;
+            if (xf > v[11] || xf < v[10] || yf > v[13] || yf < v[12]) continue;
+            const float x0 = v[0], y0 = v[1], x1 = v[3], y1 = v[4], x2 = v[6], y2 = v[7];
+            const float e0 = (xf - x1) * v[14] - (yf - y1) * v[15];
+            const float e1 = (xf - x2) * v[16] - (yf - y2) * v[17];
+            const float e2 = (xf - x0) * v[18] - (yf - y0) * v[19];
+            const float area = v[9];
+            // w_i = e_i / area > 0 needs e_i != 0 and sign(e_i) == sign(area): decided without the three divisions for the pixels of the box
+            // that lie outside the triangle (area == 0 -> inf / NaN quotients: left to the exact path)
+            if (area != 0.0f && (e0 == 0.0f || (e0 < 0.0f) != (area < 0.0f) || e1 == 0.0f || (e1 < 0.0f) != (area < 0.0f) || e2 == 0.0f ||
+                                 (e2 < 0.0f) != (area < 0.0f)))
+                continue;
+            const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+            const float pz = w0 * v[2] + w1 * v[5] + w2 * v[8];
             if (pz < 0) continue;
             if (!((w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f))) continue;
             const int f = sfid[j];
@@ -263,9 +302,10 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
     SMIRK_LAUNCH(raster_face_setup, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, transformed,
                        frec, fbox);
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-    const size_t smem = FACE_CHUNK * 9 * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
+    const size_t smem = FACE_CHUNK * FACE_REC * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
+    static const char* abl = getenv("SMIRK_RASTER_ABLATE");      // 1: no per-pixel face loop, 2: no binning scan (timing experiments; wrong images)
     SMIRK_LAUNCH(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
-                       (long long*)pix_to_face, bary, zbuf);
+                       (long long*)pix_to_face, bary, zbuf, abl ? atoi(abl) : 0);
     return smirk_launch_status();
 }
 
