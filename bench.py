@@ -547,7 +547,7 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
     dom = max(per, key=lambda k: per[k][2])
     fl, by, tm, n = per[dom]
     split = ",true," in dom or dom.endswith("true>") or dom.startswith("conv_pp_kernel")      # split-fp16 (f16x3) kernels
-    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd"))
+    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd", "wgrad_kernel"))   # wgrad: exact-fp32 MFMA
     traffic = None
     if traffic_table:
         t = traffic_table.get(dom) or traffic_table.get(dom.replace(", ", ","))

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                      double* __restrict__ part /*[blocks][C][2]*/) {
-    __shared__ double red[256 * 2];
+    __shared__ double red[256 * 16];
     const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;          // RPB rows in flight per block iteration; when G does not
     const bool active = rl < RPB;                                                   // divide 256 the last 256 - RPB*G threads only attend the barriers
     double s1[8], s2[8];
@@ -77,17 +77,16 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
             }
         }
     }
-    // reduce over the RPB row-lanes of each channel group (fixed order), one channel at a time through LDS
-    for (int q = 0; q < 8; ++q) {
-        red[tid * 2] = s1[q]; red[tid * 2 + 1] = s2[q];
-        __syncthreads();
-        if (rl == 0) {
-            double a = 0.0, b = 0.0;
-            for (int k = 0; k < RPB; ++k) { a += red[(k * G + g) * 2]; b += red[(k * G + g) * 2 + 1]; }
-            double* o = part + ((size_t)blockIdx.x * G * 8 + g * 8 + q) * 2;
-            o[0] = a; o[1] = b;
-        }
-        __syncthreads();
+    // reduce over the RPB row lanes of each channel group in a fixed order (row lane 0, 1, ...): all 16 sums of a thread go to LDS at once and
+    // G * 16 threads each add up one (group, channel, which) column — one barrier, not sixteen, and no single thread walking 64 entries 8 times
+    // (that serial tail, not the streaming loop, was most of this kernel: 2.1 TB/s)
+    for (int q = 0; q < 8; ++q) { red[tid * 16 + q * 2] = s1[q]; red[tid * 16 + q * 2 + 1] = s2[q]; }
+    __syncthreads();
+    for (int o = tid; o < G * 16; o += 256) {
+        const int gg = o >> 4, k = o & 15;
+        double a = 0.0;
+        for (int r = 0; r < RPB; ++r) a += red[(r * G + gg) * 16 + k];
+        part[((size_t)blockIdx.x * G * 8 + gg * 8 + (k >> 1)) * 2 + (k & 1)] = a;
     }
 }
 
@@ -551,7 +550,8 @@ static int wgrad_nsplit(long long npix, int Cout, int N) {
     const long long chunks = (npix + WG_KC - 1) / WG_KC;
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const long long tiles = (long long)((Cout + TM - 1) / TM) * ((N + 127) / 128);
-    long long want = (1024 + tiles - 1) / tiles;                       // ~4 workgroups per CU
+    long long want = (TM == 128 ? 1024 : 1536) / tiles;                // 4 (TM = 128: 34 KB LDS each) / 6 workgroups per CU in ONE round (rounding up put 1152 on
+                                                                       // 1024 slots for the 512-channel layers: a second, 12 % full round)
     if (want > WG_MAX_SPLIT) want = WG_MAX_SPLIT;
     if (want > chunks) want = chunks;
     return (int)(want < 1 ? 1 : want);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
 #define DW_RED_BLOCKS 256
 __global__ __launch_bounds__(256) void dw_wgrad_stage1(const float* __restrict__ dz, const float* __restrict__ x, int B, int H, int W, int G, int stride,
                                                        double* __restrict__ part /*[blocks][C][9]*/) {
-    __shared__ double red[256];
+    __shared__ float red[256 * 24];
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const int pt = pad_lead(H, stride), pl = pad_lead(W, stride);
     const int tid = threadIdx.x, RPB = 256 / G, g = tid % G, rl = tid / G;
@@ -114,17 +114,21 @@ __global__ __launch_bounds__(256) void dw_wgrad_stage1(const float* __restrict__
                 }
             }
         }
-    for (int k = 0; k < 9; ++k)
-        for (int q = 0; q < 8; ++q) {
-            red[tid] = active ? (double)acc[k][q] : 0.0;
-            __syncthreads();
-            if (rl == 0) {
-                double s = 0.0;
-                for (int j = 0; j < RPB; ++j) s += red[j * G + g];
-                part[((size_t)blockIdx.x * G * 8 + g * 8 + q) * 9 + k] = s;
-            }
-            __syncthreads();
+    // combine the row lanes (fixed order) three taps at a time: 24 sums per thread through LDS, G * 24 threads each add one column in fp64
+    for (int k0 = 0; k0 < 9; k0 += 3) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[tid * 24 + k * 8 + q] = active ? acc[k0 + k][q] : 0.f;
+        __syncthreads();
+        for (int o = tid; o < G * 24; o += 256) {
+            const int gg = o / 24, e = o % 24, k = k0 + e / 8, q = e % 8;
+            double sum = 0.0;
+            for (int j = 0; j < RPB; ++j) sum += (double)red[(j * G + gg) * 24 + e];
+            part[((size_t)blockIdx.x * G * 8 + gg * 8 + q) * 9 + k] = sum;
         }
+    }
 }
 __global__ __launch_bounds__(256) void dw_wgrad_stage2(const double* __restrict__ part, int nblocks, int C, float* __restrict__ dw /*[9][C]*/) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
