@@ -174,6 +174,17 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
         ox0 = (t - (t / tiles_x) * tiles_x) * PT;
     };
     PATCH_BUF_DECL()
+    // INTERIOR patches (no halo pixel outside its image: 73 % of the patches of a 224^2 map) need no per-lane address or validity arithmetic at all:
+    // the lane's offset of slot q relative to the patch's halo origin is a per-launch constant (kept in NQ registers), the origin goes into the
+    // buffer load's SCALAR offset.  Issuing a halo patch used to cost ~380 cycles per DMA instruction in VALU address math (4.2 k cycles per patch,
+    // tools/patch_timeline.py), more than the DMA's own latency.
+    unsigned loff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pix = (q * 4 + wave) * 8 + (lane >> 3), yy = (pix * 3641) >> 16, xx = pix - yy * PH;
+        const int piece = (lane & 7) ^ ((pix >> 1) & 7);
+        loff[q] = pix < PPIXT ? (((unsigned)(yy * a.W + xx)) << bsh0) + (unsigned)piece * 16u : 0x80000000u;
+    }
     auto issue_item = [&](int item, int st) {
         int b, oy0, ox0, cc;
         item_patch(item, b, oy0, ox0, cc);
@@ -184,6 +195,14 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
         float* dst = St + st * PSTG;
         if (a.use_buf) {
             const int basepix = (b * a.H + oy0 - 1) * a.W + ox0 - 1, sh = s1 ? bsh1 : bsh0;
+            if (oy0 > 0 && oy0 + PTH < a.H && ox0 > 0 && ox0 + PT < a.W && cb + 32 <= cs && sh == bsh0) {
+                const unsigned so = (unsigned)cb * 4u + ((unsigned)basepix << sh);
+                (void)so;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if ((q * 4 + swave) * 8 < PPIXT) PATCH_BUF_LOAD(s1, dst + (q * 4 + swave) * 8 * 32, loff[q], so);
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if ((q * 4 + swave) * 8 < PPIXT) {
@@ -427,6 +446,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         ox0 = (t - (t / tiles_x) * tiles_x) * PT;
     };
     PATCH_BUF_DECL()
+    unsigned loff[NQ];                                           // interior patches: per-lane slot offsets, origin in the scalar offset (see conv3x3_patch_kernel)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pix = (q * 4 + wave) * 8 + (lane >> 3), yy = (pix * 3641) >> 16, xx = pix - yy * PH;
+        const int piece = (lane & 7) ^ ((pix >> 1) & 7);
+        loff[q] = pix < PPIX ? (((unsigned)(yy * a.W + xx)) << bsh0) + (unsigned)piece * 16u : 0x80000000u;
+    }
     auto issue_input = [&](int p, int cc, int st) {
         int b, oy0, ox0;
         patch_origin(p, b, oy0, ox0);
@@ -437,6 +463,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         float* dst = St + st * PSTAGE;
         if (a.use_buf) {
             const int basepix = (b * a.H + oy0 - 1) * a.W + ox0 - 1, sh = s1 ? bsh1 : bsh0;
+            if (oy0 > 0 && oy0 + PT < a.H && ox0 > 0 && ox0 + PT < a.W && sh == bsh0) {
+                const unsigned so = (unsigned)cb * 4u + ((unsigned)basepix << sh);
+                (void)so;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if ((q * 4 + swave) * 8 < PPIX) PATCH_BUF_LOAD(s1, dst + (q * 4 + swave) * 8 * 32, loff[q], so);
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if ((q * 4 + swave) * 8 < PPIX) {
