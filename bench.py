@@ -282,7 +282,7 @@ def pmc_parse(db_dir, counter):
     name_col = "kernel_name" if "kernel_name" in cols else "name"
     agg = {}
     for k, v in c.execute(f"select {name_col}, value from counters_collection where counter_name = ?", (counter,)):
-        k = k.split("(")[0].replace("void ", "").replace(", ", ",")
+        k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace(", ", ",")
         a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(v)
     return agg
 
@@ -550,8 +550,13 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
     gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd", "wgrad_kernel"))   # wgrad: exact-fp32 MFMA
     traffic = None
     if traffic_table:
-        t = traffic_table.get(dom) or traffic_table.get(dom.replace(", ", ","))
+        key = dom.split("[")[0]                                   # the profiler appends a "[tile,waves,stages]" tag to some names
+        t = traffic_table.get(dom) or traffic_table.get(key) or traffic_table.get(key.replace(", ", ","))
         traffic = (t["bytes_per_launch"] if isinstance(t, dict) else t) if t is not None else None
+    # a GEMM-shaped launch whose arithmetic intensity sits below the ridge point (MFMA peak of its arithmetic mode / HBM peak) is priced against HBM:
+    # the encoder's 1x1 convolutions over 16-72 channels move 4 bytes per 8-36 flop
+    if gemm and fl > 0 and by > 0 and fl / by < ((PEAK_F16_MFMA / 3.0) if split else PEAK_FP32_MFMA) / PEAK_HBM:
+        gemm = False
     if gemm and fl > 0:
         peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
         roof = {"bound": "mfma", "kernel": dom, "achieved": fl / tm / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / tm / peak,

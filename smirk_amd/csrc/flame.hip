@@ -587,6 +587,10 @@ extern "C" int smirk_flame_forward(const SmirkFlameModel* m, int B, const float*
     SMIRK_LAUNCH(flame_prologue, dim3(B), dim3(64), 0, st, d, B, shape, ns_in, expr, ne_in, global_pose, neck, jaw,
                        eye, coef, amat, lut);
     dim3 grid(m->VP / FL_BV, (B + FL_BM - 1) / FL_BM);
+    // algorithmic work: blendshape GEMM [B x KP] x [KP x 3 V] (fp32 MFMA) + skinning; bytes: the fp32 basis once (L2/MALL-resident across the grid's
+    // batch tiles), coefficients, skinning weights, vertices out
+    smirk_prof_next(nullptr, 2.0 * B * (double)m->KP * 3.0 * m->V + 2.0 * B * 3.0 * m->V * 60.0,
+                    4.0 * ((double)m->KP * 3.0 * m->VP + (double)B * m->KP + (double)m->V * 5 + (double)B * 3.0 * m->V));
     SMIRK_LAUNCH(flame_blend_skin, grid, dim3(256), 0, st, d, B, coef, amat, eyelid, verts, v_posed_out);
     SMIRK_LAUNCH(flame_landmarks, dim3(B), dim3(256), 0, st, d, B, verts, lut, lmk_fan, lmk_fan3d, lmk_mp);
     if (lut_idx_out) {

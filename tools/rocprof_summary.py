@@ -7,7 +7,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     if "at::native" in name:
         return "torch::" + name.split("at::native::")[1].split("<")[0].split("(")[0]
     return name.split("(")[0]
