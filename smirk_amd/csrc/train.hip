@@ -12,6 +12,7 @@
 // are "k-major" in memory, which is exactly the operand layout of v_mfma_f32_32x32x2_f32 (one fp32 per lane: lanes 0-31 / 32-63 hold k, k+1) —
 // no transposition is needed, and the gradient is accumulated in exact fp32.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "conv_common.h"
 
@@ -60,20 +61,32 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
 #pragma unroll
         for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
     }
-    for (size_t r = (size_t)blockIdx.x * RPB + rl; active && r < M; r += (size_t)gridDim.x * RPB) {
-        float v[8];
-        load_group(z + (r * G + g) * 8, v);
-        if (MODE == 0) {
+    // four rows per iteration: all their loads are issued before the first is consumed.  One row in flight per thread (8 waves per CU x 2 KB) is
+    // 16 KB per CU against ~2 us of HBM latency = the 2.1-2.6 TB/s this kernel measured; the accumulation order per thread stays row-ascending.
+    const size_t S = (size_t)gridDim.x * RPB;
+    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += 4 * S) {
+        float v[4][8], d[4][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { s1[q] += (double)v[q]; s2[q] += (double)v[q] * (double)v[q]; }
-        } else {
-            float d[8];
-            load_group(dy + (r * G + g) * 8, d);
+        for (int u = 0; u < 4; ++u) {
+            const size_t r = r0 + u * S;
+            if (r < M) {
+                load_group(z + (r * G + g) * 8, v[u]);
+                if (MODE == 1) load_group(dy + (r * G + g) * 8, d[u]);
+            }
+        }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float xh = (v[q] - mu[q]) * is[q];
-                const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[q];
-                s1[q] += (double)dh; s2[q] += (double)dh * (double)xh;
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u * S >= M) break;
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { s1[q] += (double)v[u][q]; s2[q] += (double)v[u][q] * (double)v[u][q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float xh = (v[u][q] - mu[q]) * is[q];
+                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
+                    s1[q] += (double)dh; s2[q] += (double)dh * (double)xh;
+                }
             }
         }
     }
@@ -412,6 +425,110 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             }
         }
 }
+// Weight gradient of a 3x3 zero-padded convolution with FEW channels (the U-Net's 224^2 / 112^2 layers: Cout, Cin in {32, 64}).  There the generic kernel is
+// bound by the L2 -> CU path, not by MFMA: a 32 x 128 tile re-loads 10 KB of operands for 131 kflop (13 flop/B, 36 TFLOP/s measured).  Here one workgroup owns ALL
+// nine taps of its pixel chunk: the chunk is 16 consecutive pixels of one image row, x is staged ONCE as a [3 rows][18 pixels][Cin] halo and every tap reads its
+// B fragment from that halo at a pixel offset — 9 KB per chunk for 295 kflop at Cin = Cout = 32 (33 flop/B).  The (Cout/32) x 9 x (Cin/32) MFMA blocks are dealt
+// round-robin to the 4 waves; LDS double-buffered, next chunk's loads in flight under the MFMAs, K split over chunks like the generic kernel (same partial layout).
+template <int TM, int CIN>
+__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(WgradArgs a) {
+    constexpr int LDA = TM + 4, LDB = CIN + 4, HPX = 3 * 18;
+    constexpr int NB = (TM / 32) * 9 * (CIN / 32), MAXB = (NB + 3) / 4;
+    constexpr int GA = TM / 8, GB = CIN / 8;                                   // 8-channel groups per pixel
+    constexpr int NLB = (HPX * GB + 255) / 256;                               // B groups per thread and chunk
+    __shared__ __attribute__((aligned(16))) float As[2][WG_KC * LDA], Bs[2][HPX * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x;
+    const int cpr = a.W / 16;                                                  // chunks per image row
+    const long long nchunk = (long long)a.B * a.H * cpr;
+    f32x16 acc[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float va[8], vb[NLB][8];
+    auto fetch = [&](int c) {
+        const long long ch = (long long)split * a.chunks_per_split + c;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) va[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NLB; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vb[u][q] = 0.f;
+        if (ch >= nchunk) return;
+        const int xc = (int)(ch % cpr), y = (int)((ch / cpr) % a.H);
+        const long long b = ch / ((long long)cpr * a.H);
+        const int x0 = xc * 16;
+        if (tid < WG_KC * GA) {                                                // dz: 16 pixels x GA groups
+            const int k = tid / GA, g = tid % GA;
+            load_group(a.dz + ((((size_t)b * a.H + y) * a.W + x0 + k) * GA + g) * 8, va);
+        }
+#pragma unroll
+        for (int u = 0; u < NLB; ++u) {
+            const int e = tid + u * 256;
+            if (e < HPX * GB) {
+                const int hp = e / GB, g = e % GB, hy = hp / 18, hx = hp % 18;
+                const int iy = y - 1 + hy, ix = x0 - 1 + hx;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) load_group(a.x + ((((size_t)b * a.H + iy) * a.W + ix) * GB + g) * 8, vb[u]);
+            }
+        }
+    };
+    // this wave's MFMA blocks: blk = wave + 4 i  ->  (m block, tap, n block)
+    int boffA[MAXB], boffB[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + 4 * i, mb = blk / (9 * (CIN / 32)), rem = blk % (9 * (CIN / 32)), tap = rem / (CIN / 32), nb = rem % (CIN / 32);
+        boffA[i] = mb * 32;
+        boffB[i] = ((tap / 3) * 18 + (tap % 3)) * LDB + nb * 32;               // halo pixel offset of the tap: row ky, column kx (pixel k sits at column k + 1 - 1 + kx)
+    }
+    fetch(0);
+    for (int c = 0; c < a.chunks_per_split; ++c) {
+        float* as = As[c & 1];
+        float* bs = Bs[c & 1];
+        if (tid < WG_KC * GA) {
+            const int k = tid / GA, g = tid % GA;
+            *(f32x4*)(as + k * LDA + g * 8) = *(f32x4*)va; *(f32x4*)(as + k * LDA + g * 8 + 4) = *(f32x4*)(va + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NLB; ++u) {
+            const int e = tid + u * 256;
+            if (e < HPX * GB) {
+                const int hp = e / GB, g = e % GB;
+                *(f32x4*)(bs + hp * LDB + g * 8) = *(f32x4*)vb[u]; *(f32x4*)(bs + hp * LDB + g * 8 + 4) = *(f32x4*)(vb[u] + 4);
+            }
+        }
+        __syncthreads();
+        if (c + 1 < a.chunks_per_split) fetch(c + 1);
+        const int kk = lane >> 5, mm = lane & 31;
+#pragma unroll
+        for (int k2 = 0; k2 < WG_KC; k2 += 2) {
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                if (wave + 4 * i < NB) {
+                    const float fa = as[(k2 + kk) * LDA + boffA[i] + mm];
+                    const float fb = bs[(k2 + kk) * LDB + boffB[i] + mm];      // pixel k of the chunk under tap (ky, kx) = halo (ky, k + kx)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int N = 9 * CIN;
+    float* out = a.part + (size_t)split * a.Cout * N;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + 4 * i;
+        if (blk < NB) {
+            const int mb = blk / (9 * (CIN / 32)), rem = blk % (9 * (CIN / 32)), tap = rem / (CIN / 32), nb = rem % (CIN / 32);
+            const int n = tap * CIN + nb * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mb * 32 + mfma32_row(r, lane);
+                out[(size_t)co * N + n] = acc[i][r];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ dw) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // 8 independent chains keep 8 loads in flight; combined in a fixed order
@@ -546,8 +663,17 @@ extern "C" int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const flo
     return smirk_launch_status();
 }
 
+static bool wgrad_halo_ok(int W, int Cout, int Cin, int KH, int reflect) {
+    static const char* off = getenv("SMIRK_WGRAD_HALO");                     // "0" forces the generic kernel (A/B)
+    return KH == 3 && !reflect && W % 16 == 0 && (Cout == 32 || Cout == 64) && (Cin == 32 || Cin == 64) && !(off && off[0] == '0');
+}
 static int wgrad_nsplit(long long npix, int Cout, int N) {
     const long long chunks = (npix + WG_KC - 1) / WG_KC;
+    if (N % 9 == 0 && (Cout == 32 || Cout == 64) && (N == 288 || N == 576)) {  // halo kernel (when eligible): one workgroup per split, ~6 per CU
+        long long want = (Cout == 64 && N == 576) ? 1024 : 1536;               // 38 KB LDS -> 4 per CU, else 20-29 KB -> 6 per CU
+        if (want > chunks) want = chunks;
+        return (int)want;
+    }
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const long long tiles = (long long)((Cout + TM - 1) / TM) * ((N + 127) / 128);
     long long want = (TM == 128 ? 1024 : 1536) / tiles;                // 4 (TM = 128: 34 KB LDS each) / 6 workgroups per CU in ONE round (rounding up put 1152 on
@@ -567,6 +693,21 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
     if (ws_bytes < smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH)) return SMIRK_ERR_WORKSPACE;
     const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
     const int N = KH * KH * Cin, nsplit = wgrad_nsplit(npix, Cout, N);
+    if (wgrad_halo_ok(W, Cout, Cin, KH, reflect)) {                          // few-channel 3x3 layers: all nine taps from one staged halo
+        WgradArgs h;
+        h.dz = (const float*)dz; h.x = (const float*)x; h.part = (float*)ws;
+        h.B = B; h.H = H; h.W = W; h.Cout = Cout; h.Cin = Cin; h.KH = 3; h.pad = 1; h.reflect = 0;
+        h.chunks_per_split = (int)((chunks + nsplit - 1) / nsplit);          // W % 16 == 0: a 16-pixel chunk never crosses a row
+        hipStream_t hs = (hipStream_t)stream;
+        smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
+        if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 32>), dim3(nsplit), dim3(256), 0, hs, h);
+        else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 32>), dim3(nsplit), dim3(256), 0, hs, h);
+        else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 64>), dim3(nsplit), dim3(256), 0, hs, h);
+        else SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 64>), dim3(nsplit), dim3(256), 0, hs, h);
+        const size_t nh = (size_t)Cout * N;
+        SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(nh, 4096)), dim3(256), 0, hs, (const float*)ws, nsplit, nh, dw);
+        return smirk_launch_status();
+    }
     WgradArgs a;
     a.dz = (const float*)dz; a.x = (const float*)x; a.part = (float*)ws;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.pad = (KH - 1) / 2; a.reflect = reflect;

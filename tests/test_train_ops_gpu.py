@@ -82,7 +82,10 @@ def test_batchnorm_train_forward_backward(shape, relu, res):
 
 @pytest.mark.parametrize("B,H,W,cin,cout,k,reflect", [(2, 8, 8, 32, 64, 3, False), (3, 4, 4, 512, 512, 3, True), (1, 3, 3, 512, 512, 3, True),
                                                        (2, 2, 2, 512, 512, 3, True), (2, 16, 12, 8, 32, 3, False), (1, 64, 64, 32, 32, 3, False),
-                                                       (2, 8, 8, 32, 8, 1, False), (2, 6, 6, 256, 512, 1, False)])
+                                                       (2, 8, 8, 32, 8, 1, False), (2, 6, 6, 256, 512, 1, False),
+                                                       # few-channel 3x3 layers with W % 16 == 0: the all-taps halo kernel (32/64 x 32/64 channels), ragged K splits
+                                                       (2, 16, 16, 32, 32, 3, False), (1, 48, 32, 64, 32, 3, False), (3, 16, 48, 32, 64, 3, False),
+                                                       (1, 32, 16, 64, 64, 3, False), (2, 112, 112, 64, 64, 3, False)])
 def test_conv_weight_gradient(B, H, W, cin, cout, k, reflect):
     """smirk_conv_wgrad_f32 (exact fp32 MFMA, split-K) against autograd's weight gradient"""
     T, ops = _ops()
@@ -340,3 +343,25 @@ def test_pool_linear_head_backward(B, hw, C, N):
     L.check(ops.lib.smirk_gap_linear_backward_split16(L.ptr(go.cuda().contiguous()), L.ptr(wg), L.ptr(pooled), L.ptr(dw), L.ptr(db), L.ptr(df), B, h * h, C, N,
                                                       ops.st))
     assert _rel(dw.cpu(), w64.grad) < TOL and _rel(db.cpu(), b64.grad) < TOL and _rel(_val(df), f.grad) < TOL
+
+
+@pytest.mark.parametrize("cout,cin,k,off,sub,pad", [(32, 6, 3, 0, None, 8), (64, 32, 3, 0, None, None), (32, 64, 3, 32, 32, None), (512, 512, 3, 0, None, None),
+                                                   (24, 72, 1, 0, None, None), (960, 160, 1, 0, None, None)])
+def test_weight_packing_kernel_is_bitwise_the_torch_packing(cout, cin, k, off, sub, pad):
+    """smirk_pack_conv_weights_split16 (one launch: forward image + 180-degree rotated, Cin<->Cout swapped data-gradient image, optional input-channel
+    slice and zero channel padding) against the torch formulation the per-op tests above are written with"""
+    T, ops = _ops()
+    g = _gen(cout + cin + k)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.3).cuda()
+    n = cin - off if sub is None else sub
+    fwd, dgr = ops.pack(w, off, n, cin_pad=pad)
+    ws = w[:, off:off + n]
+    if k == 3:
+        want_f = T._pack_fwd(ws, pad)
+        want_d = T._pack_dgrad(ws, pad)
+    else:
+        from smirk_amd.smirk_generator import _split16
+        want_f = _split16(ws.reshape(cout, n).contiguous())
+        want_d = _split16(ws.reshape(cout, n).t().contiguous())
+    assert fwd.shape == want_f.shape and torch.equal(fwd.view(torch.int32), want_f.view(torch.int32))
+    assert dgr.shape == want_d.shape and torch.equal(dgr.view(torch.int32), want_d.view(torch.int32))
