@@ -382,9 +382,14 @@ int smirk_space_to_depth2_split16(const void* in, void* out, int B, int H, int W
  * conv input) and dl8[B][H][W][8] split16 (dL/dlogits, channels >= Cout zero) from which smirk_conv_wgrad_f32 / smirk_colsum_split16 give dW and db. */
 int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const float* y, const float* w, void* dd, void* dl8, int B, int H, int W, int C, int Cout,
                                            void* stream);
-/* Weight gradient of a KHxKH (1 or 3), stride-1, pad-(KH-1)/2 (zero or reflect) convolution in exact fp32 (v_mfma_f32_32x32x2_f32):
+/* Weight gradient of a KHxKH (1 or 3), stride-1, pad-(KH-1)/2 (zero or reflect) convolution (autograd's grad_weight of the nn.Conv2d layers in
+ * smirk_generator.py:88-178 / the timm pointwise convolutions), fp32 result:
  * dw[Cout][(ky,kx,ci)] = sum_p dz[p][co] * x[p + (ky,kx) - pad][ci]   — the packed forward weight layout.  ConvTranspose2d(k=2,s=2): call with KH = 1,
- * dz = the layer INPUT [M][Cin_t] and x = space_to_depth2(output gradient) [M][4*Cout_t] => dw[Cin_t][(dy,dx,co)]. */
+ * dz = the layer INPUT [M][Cin_t] and x = space_to_depth2(output gradient) [M][4*Cout_t] => dw[Cin_t][(dy,dx,co)].
+ * Arithmetic: split-fp16 x3 on the fp16 matrix pipe (operands are consumed as stored, transposed by ds_read_b64_tr_b16; fp32 accumulate, fp32-class error
+ * like the forward convolutions) by default, or the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).  smirk_conv_wgrad_set_mode: 0 = exact fp32,
+ * 1 / 2 = split-fp16 x3 with 1 / 2 pixel chunks per barrier, -1 = back to $SMIRK_WGRAD_F16 / the built-in default; returns the previous mode. */
+int smirk_conv_wgrad_set_mode(int mode);
 /* nn.Conv2d weight [Cout][cin_total][KH][KH] fp32 (KH 1 or 3), input-channel slice [cin_off, cin_off + Cin) (a U-Net decoder conv reads two sources)
  * -> the step's two split16 operand images in ONE launch (either may be NULL):
  * fwd [Cout][(ky,kx,c)], c < cin_pad (zeros beyond Cin) and dgrad [cin_pad][(ky,kx,co)] = W rotated by 180 degrees with Cin <-> Cout swapped. */

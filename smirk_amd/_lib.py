@@ -135,6 +135,7 @@ _SIGS = {
     "smirk_reflect_pad1_backward_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_space_to_depth2_split16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "smirk_conv1x1_sigmoid_backward_split16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "smirk_conv_wgrad_set_mode": (_i, [_i]),
     "smirk_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_pack_conv_weights_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void final_backward_kernel(const float* __rest
 #define WG_KC 16
 #define WG_LD 132
 #define WG_MAX_SPLIT 512
+#define SMIRK_WGRAD_F16_DEFAULT 2
 struct WgradArgs {
     const float *dz, *x;         // split16 [B][H][W][Cout], [B][H][W][Cin]
     float* part;
@@ -425,6 +426,153 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             }
         }
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the fp16 matrix pipe: split-fp16 x3 (acc0 += dz_hi.x_hi ; acc1 += dz_hi.x_lo + dz_lo.x_hi ; dW = acc0 + acc1 * 2^-11 — fp16 x fp16 products
+// are exact in fp32, only the 2^-22 lo.lo term is dropped: the arithmetic of the forward convolutions), 3 x v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block
+// = 96 matrix-pipe cycles where the exact-fp32 instruction needs 512.  Both operands are ALREADY split16 in HBM, so nothing is converted; what the fp16
+// instruction needs and memory does not offer is k (= pixel) contiguity per lane — 8 consecutive pixels of one channel — while memory is channel-contiguous
+// per pixel.  gfx950's LDS transpose read does that re-arrangement for free: `ds_read_b64_tr_b16` lets the 16 lanes of a group fetch a [4 pixels][16 channels]
+// block (lane 4r+q supplies the 8-byte address of pixel r, channels 4q..4q+3) and returns to lane c the four pixels of channel c.  Two such reads make one
+// MFMA operand (pixels 8*(lane>>5) + 0..7 of channel lane&31); the pixel <-> (lane half, element) assignment is the same for both operands, which is all a
+// reduction index has to satisfy.
+// LDS image of a 16-pixel chunk of an operand with NG 8-channel groups, in 16-byte slots (one slot = the hi OR the lo halves of one group of one pixel):
+//     slot(h, g, k) = ((h * NG/4 + g/4) * 4 + k/4) * 16  +  ((k%4 + g/4) % 4) * 4  +  g%4
+// i.e. every aligned 256-byte bank row holds 4 pixels x 4 groups of one half.  A half-wave's transpose read (4 pixels x 32 channels = 4 groups) covers exactly
+// one bank row -> conflict-free; the staging writes (`ds_write_b128`, 8 lanes = 8 consecutive groups of one pixel per LDS cycle) land on 8 distinct 16-byte
+// bank slots because the row rotation by g/4 flips the slot's bit 2 between groups 0-3 and 4-7.
+// Staging is register-based (global 16-byte loads of the raw hi / lo pieces, issued a chunk ahead, under the MFMAs), double-buffered, one barrier per SUB chunks.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4_t* lds_fp16x4_ptr;
+
+__device__ __forceinline__ int wgf_slot(int ngq, int kq_per, int h, int g, int k) {      // 16-byte slot of (half h, group g, pixel k); kq_per = pixel quads per image
+    return ((h * ngq + (g >> 2)) * kq_per + (k >> 2)) * 16 + ((((k & 3) + (g >> 2)) & 3) << 2) + (g & 3);
+}
+__device__ __forceinline__ half8 wgf_frag(const char* base, int off) {                    // two transpose reads -> one 32x32x16 MFMA operand (8 pixels of this lane's channel)
+    union { fp16x4_t v[2]; half8 h; } u;
+    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(base + off));
+    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_ptr)(base + off + 256));
+    return u.h;
+}
+
+template <int TM, int SUB>
+__global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trmap) {
+    constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
+    constexpr int BM = TM / 32 / WAVES_M, BN = 4 / WAVES_N;                 // 32 x 32 MFMA blocks per wave: 2x2 (TM 128), 2x1 (TM 64), 1x1 (TM 32)
+    constexpr int GA = TM / 8, AQ = GA / 4, BQ = 4;                         // 8-channel groups / group quads of the A (dz) and B (x, 128 columns) tiles
+    constexpr int A_BYTES = GA * 2 * 16 * 16, B_BYTES = 16 * 2 * 16 * 16;   // one 16-pixel chunk image
+    __shared__ __attribute__((aligned(256))) char As[2][SUB][A_BYTES];
+    __shared__ __attribute__((aligned(256))) char Bs[2][SUB][B_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int N = a.KH * a.KH * a.Cin;
+    const int co0 = blockIdx.x * TM, n0 = blockIdx.y * 128, split = blockIdx.z;
+    const long long npix = (long long)a.B * a.H * a.W;
+    f32x16 acc0[BM][BN], acc1[BM][BN];
+#pragma unroll
+    for (int i = 0; i < BM; ++i)
+#pragma unroll
+        for (int j = 0; j < BN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+    // staging: thread -> (pixel sk, 8-wide group sg) of every 16-pixel chunk: the group's raw 32 bytes (hi piece, lo piece)
+    const int sk = tid >> 4, sg = tid & 15;
+    const int Gout = a.Cout / 8, Gin = a.Cin / 8;
+    const int gco = co0 / 8 + sg;
+    const bool a_on = sg < GA && gco < Gout;
+    const int nb = n0 + sg * 8;
+    const bool b_on = nb < N;
+    const int tap = b_on ? nb / a.Cin : 0, gci = b_on ? (nb % a.Cin) / 8 : 0;
+    const int ky = tap / a.KH, kx = tap % a.KH;
+    const int wa_hi = wgf_slot(AQ, 4, 0, sg, sk) * 16, wa_lo = wgf_slot(AQ, 4, 1, sg, sk) * 16;
+    const int wb_hi = wgf_slot(BQ, 4, 0, sg, sk) * 16, wb_lo = wgf_slot(BQ, 4, 1, sg, sk) * 16;
+    const int iters = (a.chunks_per_split + SUB - 1) / SUB;
+    // the pixel this thread stages in the NEXT chunk, kept decomposed (image, row, column) and advanced by 16 per chunk: no divisions in the loop
+    const long long p0 = (long long)split * a.chunks_per_split * WG_KC + sk;
+    int fb = (int)(p0 / ((long long)a.W * a.H));
+    int fy, fx;
+    { const int rem = (int)(p0 - (long long)fb * a.W * a.H); fy = rem / a.W; fx = rem - fy * a.W; }
+    int fc = 0;
+    uint4 ra[SUB][2], rb[SUB][2];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            ra[s][0] = ra[s][1] = rb[s][0] = rb[s][1] = make_uint4(0u, 0u, 0u, 0u);
+            if (fc < a.chunks_per_split && fb < a.B) {
+                if (a_on) {
+                    const uint4* q = (const uint4*)(a.dz + ((size_t)(p0 + (long long)fc * WG_KC) * Gout + gco) * 8);
+                    ra[s][0] = q[0]; ra[s][1] = q[1];
+                }
+                if (b_on) {
+                    int iy = fy + ky - a.pad, ix = fx + kx - a.pad;
+                    bool ok = true;
+                    if (a.reflect) { iy = reflect_idx(iy, a.H); ix = reflect_idx(ix, a.W); }
+                    else ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    if (ok) {
+                        const uint4* q = (const uint4*)(a.x + ((((size_t)fb * a.H + iy) * a.W + ix) * Gin + gci) * 8);
+                        rb[s][0] = q[0]; rb[s][1] = q[1];
+                    }
+                }
+            }
+            ++fc;
+            fx += WG_KC;
+            while (fx >= a.W) { fx -= a.W; if (++fy == a.H) { fy = 0; ++fb; } }
+        }
+    };
+    // transpose-read lane geometry: 16-lane group -> [4 pixels][16 channels]; lane i of the group supplies pixel r, channel quarter q
+    const int li = lane & 15, r4 = trmap ? (li & 3) : (li >> 2), q4 = trmap ? (li >> 2) : (li & 3);
+    const int gl = ((lane >> 4) & 1) * 2 + (q4 >> 1), khalf = lane >> 5;    // group within the block's quad; pixels 8*khalf.. of the chunk
+    int offA[BM], offB[BN];                                                  // byte offset of (half hi, first read) inside a chunk image
+#pragma unroll
+    for (int i = 0; i < BM; ++i) {
+        const int gq = wm * BM + i;
+        offA[i] = (((gq * 4 + khalf * 2) * 16) + (((r4 + gq) & 3) << 2) + gl) * 16 + (q4 & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < BN; ++j) {
+        const int gq = wn * BN + j;
+        offB[j] = (((gq * 4 + khalf * 2) * 16) + (((r4 + gq) & 3) << 2) + gl) * 16 + (q4 & 1) * 8;
+    }
+    fetch();
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            if (sg < GA) { *(uint4*)(As[buf][s] + wa_hi) = ra[s][0]; *(uint4*)(As[buf][s] + wa_lo) = ra[s][1]; }
+            *(uint4*)(Bs[buf][s] + wb_hi) = rb[s][0]; *(uint4*)(Bs[buf][s] + wb_lo) = rb[s][1];
+        }
+        __syncthreads();                       // this stage visible; the stage written next iteration was last read two iterations ago, behind this barrier
+        if (it + 1 < iters) fetch();
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            half8 ah[BM], al[BM], bh[BN], bl[BN];
+#pragma unroll
+            for (int i = 0; i < BM; ++i) { ah[i] = wgf_frag(As[buf][s], offA[i]); al[i] = wgf_frag(As[buf][s], offA[i] + AQ * 1024); }
+#pragma unroll
+            for (int j = 0; j < BN; ++j) { bh[j] = wgf_frag(Bs[buf][s], offB[j]); bl[j] = wgf_frag(Bs[buf][s], offB[j] + BQ * 1024); }
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+#pragma unroll
+                for (int j = 0; j < BN; ++j) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float* out = a.part + (size_t)split * a.Cout * N;
+#pragma unroll
+    for (int i = 0; i < BM; ++i)
+#pragma unroll
+        for (int j = 0; j < BN; ++j) {
+            const int n = n0 + (wn * BN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * BM + i) * 32 + mfma32_row(r, lane);
+                if (co < a.Cout && n < N) out[(size_t)co * N + n] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+            }
+        }
+}
+
 // Weight gradient of a 3x3 zero-padded convolution with FEW channels (the U-Net's 224^2 / 112^2 layers: Cout, Cin in {32, 64}).  There the generic kernel is
 // bound by the L2 -> CU path, not by MFMA: a 32 x 128 tile re-loads 10 KB of operands for 131 kflop (13 flop/B, 36 TFLOP/s measured).  Here one workgroup owns ALL
 // nine taps of its pixel chunk: the chunk is 16 consecutive pixels of one image row, x is staged ONCE as a [3 rows][18 pixels][Cin] halo and every tap reads its
@@ -524,6 +672,147 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = mb * 32 + mfma32_row(r, lane);
                 out[(size_t)co * N + n] = acc[i][r];
+            }
+        }
+    }
+}
+
+// The all-taps halo kernel on the fp16 matrix pipe (split-fp16 x3, LDS transpose reads; see wgrad_f16_kernel for the arithmetic and the slot layout).
+// Chunk = 16 consecutive pixels of one image row.  A image: dz [16 pixels][TM channels]; B image: the x halo [3 rows x 18 pixels -> 54 halo pixels, padded to 14
+// pixel quads][CIN channels].  The B fragment of tap (ky, kx) for chunk pixel k is halo pixel ky*18 + kx + k: a per-lane constant added to the pixel index, so
+// the shifted fragments of all nine taps are read from the ONE staged halo (adding 4 to a pixel index moves exactly one pixel quad, hence the second transpose
+// read of an operand is again +256 bytes).  The (TM/32) x 9 x (CIN/32) MFMA blocks are dealt round-robin to NW waves; a wave's A fragments are read once per chunk.
+template <int TM, int CIN, int NW, int SUB>
+__global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a, int trmap) {
+    constexpr int NT = NW * 64, HPX = 54, HQ = 14;
+    constexpr int MB = TM / 32, NBQ = CIN / 32;                               // 32-channel quads of A and B
+    constexpr int NB = MB * 9 * NBQ, MAXB = (NB + NW - 1) / NW;
+    constexpr int GA = TM / 8, GB = CIN / 8;
+    constexpr int A_BYTES = GA * 2 * 16 * 16, B_BYTES = GB * 2 * HQ * 4 * 16;
+    constexpr int NLA = (16 * GA + NT - 1) / NT, NLB = (HPX * GB + NT - 1) / NT;
+    __shared__ __attribute__((aligned(256))) char As[2][SUB][A_BYTES];
+    __shared__ __attribute__((aligned(256))) char Bs[2][SUB][B_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x;
+    const int cpr = a.W / 16;
+    const long long nchunk = (long long)a.B * a.H * cpr;
+    f32x16 acc0[MAXB], acc1[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[i][r] = 0.f; acc1[i][r] = 0.f; }
+    // chunk cursor (image, row, chunk of the row) of the NEXT chunk to fetch, advanced by one per chunk
+    const long long ch0 = (long long)split * a.chunks_per_split;
+    int fb = (int)(ch0 / ((long long)cpr * a.H));
+    int fy, fxc;
+    { const int rem = (int)(ch0 - (long long)fb * cpr * a.H); fy = rem / cpr; fxc = rem - fy * cpr; }
+    int fc = 0;
+    uint4 ra[SUB][NLA][2], rb[SUB][NLB][2];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+#pragma unroll
+            for (int u = 0; u < NLA; ++u) ra[s][u][0] = ra[s][u][1] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) rb[s][u][0] = rb[s][u][1] = make_uint4(0u, 0u, 0u, 0u);
+            if (fc < a.chunks_per_split && fb < a.B) {
+                const int x0 = fxc * 16;
+#pragma unroll
+                for (int u = 0; u < NLA; ++u) {
+                    const int e = tid + u * NT;
+                    if (e < 16 * GA) {
+                        const int k = e / GA, g = e % GA;
+                        const uint4* q = (const uint4*)(a.dz + ((((size_t)fb * a.H + fy) * a.W + x0 + k) * GA + g) * 8);
+                        ra[s][u][0] = q[0]; ra[s][u][1] = q[1];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NLB; ++u) {
+                    const int e = tid + u * NT;
+                    if (e < HPX * GB) {
+                        const int hp = e / GB, g = e % GB, hy = hp / 18, hx = hp % 18;
+                        const int iy = fy - 1 + hy, ix = x0 - 1 + hx;
+                        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                            const uint4* q = (const uint4*)(a.x + ((((size_t)fb * a.H + iy) * a.W + ix) * GB + g) * 8);
+                            rb[s][u][0] = q[0]; rb[s][u][1] = q[1];
+                        }
+                    }
+                }
+            }
+            ++fc;
+            if (++fxc == cpr) { fxc = 0; if (++fy == a.H) { fy = 0; ++fb; } }
+        }
+    };
+    // transpose-read lane geometry (see wgrad_f16_kernel)
+    const int li = lane & 15, r4 = trmap ? (li & 3) : (li >> 2), q4 = trmap ? (li >> 2) : (li & 3);
+    const int gl = ((lane >> 4) & 1) * 2 + (q4 >> 1), khalf = lane >> 5;
+    int offA[MB], offB[MAXB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) offA[m] = (((m * 4 + khalf * 2) * 16) + (((r4 + m) & 3) << 2) + gl) * 16 + (q4 & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + NW * i, rem = blk % (9 * NBQ), tap = rem / NBQ, nbq = rem % NBQ;
+        const int hp0 = (tap / 3) * 18 + (tap % 3) + khalf * 8 + r4;            // halo pixel of chunk pixel 8*khalf + r4 under this tap
+        offB[i] = (((nbq * HQ + (hp0 >> 2)) * 16) + ((((hp0 & 3) + nbq) & 3) << 2) + gl) * 16 + (q4 & 1) * 8;
+    }
+    const int iters = (a.chunks_per_split + SUB - 1) / SUB;
+    fetch();
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+#pragma unroll
+            for (int u = 0; u < NLA; ++u) {
+                const int e = tid + u * NT;
+                if (e < 16 * GA) {
+                    const int k = e / GA, g = e % GA;
+                    *(uint4*)(As[buf][s] + wgf_slot(GA / 4, 4, 0, g, k) * 16) = ra[s][u][0];
+                    *(uint4*)(As[buf][s] + wgf_slot(GA / 4, 4, 1, g, k) * 16) = ra[s][u][1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) {
+                const int e = tid + u * NT;
+                if (e < HPX * GB) {
+                    const int hp = e / GB, g = e % GB;
+                    *(uint4*)(Bs[buf][s] + wgf_slot(GB / 4, HQ, 0, g, hp) * 16) = rb[s][u][0];
+                    *(uint4*)(Bs[buf][s] + wgf_slot(GB / 4, HQ, 1, g, hp) * 16) = rb[s][u][1];
+                }
+            }
+        }
+        __syncthreads();
+        if (it + 1 < iters) fetch();
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            half8 ah[MB], al[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { ah[m] = wgf_frag(As[buf][s], offA[m]); al[m] = wgf_frag(As[buf][s], offA[m] + (GA / 4) * 1024); }
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int blk = wave + NW * i;
+                if (blk < NB) {
+                    const half8 bh = wgf_frag(Bs[buf][s], offB[i]), bl = wgf_frag(Bs[buf][s], offB[i] + (GB / 4) * HQ * 256);
+                    half8 fah = ah[0], fal = al[0];
+                    if (MB == 2 && blk >= 9 * NBQ) { fah = ah[MB - 1]; fal = al[MB - 1]; }
+                    acc0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh, acc0[i], 0, 0, 0);
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl, acc1[i], 0, 0, 0);
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh, acc1[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int N = 9 * CIN;
+    float* out = a.part + (size_t)split * a.Cout * N;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + NW * i;
+        if (blk < NB) {
+            const int mb = blk / (9 * NBQ), rem = blk % (9 * NBQ), tap = rem / NBQ, nbq = rem % NBQ;
+            const int n = tap * CIN + nbq * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mb * 32 + mfma32_row(r, lane);
+                out[(size_t)co * N + n] = acc0[i][r] + acc1[i][r] * (1.0f / 2048.0f);
             }
         }
     }
@@ -667,6 +956,18 @@ static bool wgrad_halo_ok(int W, int Cout, int Cin, int KH, int reflect) {
     static const char* off = getenv("SMIRK_WGRAD_HALO");                     // "0" forces the generic kernel (A/B)
     return KH == 3 && !reflect && W % 16 == 0 && (Cout == 32 || Cout == 64) && (Cin == 32 || Cin == 64) && !(off && off[0] == '0');
 }
+// $SMIRK_WGRAD_F16: "0" = exact-fp32 MFMA kernel (wgrad_kernel), "1" / "2" = split-fp16 x3 kernel with 1 / 2 chunks per barrier (default 2);
+// "+16" (17 / 18) selects the alternative lane geometry of the LDS transpose read (diagnostic)
+static int g_wgrad_mode_override = -1;
+static int wgrad_f16_mode() {
+    static const int mode = [] { const char* e = getenv("SMIRK_WGRAD_F16"); return e ? atoi(e) : SMIRK_WGRAD_F16_DEFAULT; }();
+    return g_wgrad_mode_override >= 0 ? g_wgrad_mode_override : mode;
+}
+extern "C" int smirk_conv_wgrad_set_mode(int mode) {
+    const int prev = wgrad_f16_mode();
+    g_wgrad_mode_override = mode;
+    return prev;
+}
 static int wgrad_nsplit(long long npix, int Cout, int N) {
     const long long chunks = (npix + WG_KC - 1) / WG_KC;
     if (N % 9 == 0 && (Cout == 32 || Cout == 64) && (N == 288 || N == 576)) {  // halo kernel (when eligible): one workgroup per split, ~6 per CU
@@ -700,7 +1001,14 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
         h.chunks_per_split = (int)((chunks + nsplit - 1) / nsplit);          // W % 16 == 0: a 16-pixel chunk never crosses a row
         hipStream_t hs = (hipStream_t)stream;
         smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
-        if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 32>), dim3(nsplit), dim3(256), 0, hs, h);
+        const int mode = wgrad_f16_mode();
+        if (mode) {                                                          // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
+            const int trmap = (mode >> 4) & 1;
+            if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 32, 3, 2>), dim3(nsplit), dim3(192), 0, hs, h, trmap);
+            else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 32, 6, 2>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
+            else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 64, 6, 1>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
+            else SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 64, 12, 1>), dim3(nsplit), dim3(768), 0, hs, h, trmap);
+        } else if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 32>), dim3(nsplit), dim3(256), 0, hs, h);
         else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 32>), dim3(nsplit), dim3(256), 0, hs, h);
         else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 64>), dim3(nsplit), dim3(256), 0, hs, h);
         else SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 64>), dim3(nsplit), dim3(256), 0, hs, h);
@@ -716,7 +1024,19 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const dim3 grid((Cout + TM - 1) / TM, (N + 127) / 128, nsplit);
     smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
-    if (TM == 32) SMIRK_LAUNCH(wgrad_kernel<32>, grid, dim3(256), 0, st, a);
+    const int mode = wgrad_f16_mode();
+    if (mode) {                                                              // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
+        const int trmap = (mode >> 4) & 1;
+        if ((mode & 15) == 1) {
+            if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 1>), grid, dim3(256), 0, st, a, trmap);
+            else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 1>), grid, dim3(256), 0, st, a, trmap);
+            else SMIRK_LAUNCH((wgrad_f16_kernel<128, 1>), grid, dim3(256), 0, st, a, trmap);
+        } else {
+            if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 2>), grid, dim3(256), 0, st, a, trmap);
+            else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 2>), grid, dim3(256), 0, st, a, trmap);
+            else SMIRK_LAUNCH((wgrad_f16_kernel<128, 2>), grid, dim3(256), 0, st, a, trmap);
+        }
+    } else if (TM == 32) SMIRK_LAUNCH(wgrad_kernel<32>, grid, dim3(256), 0, st, a);
     else if (TM == 64) SMIRK_LAUNCH(wgrad_kernel<64>, grid, dim3(256), 0, st, a);
     else SMIRK_LAUNCH(wgrad_kernel<128>, grid, dim3(256), 0, st, a);
     const size_t n = (size_t)Cout * KH * KH * Cin;

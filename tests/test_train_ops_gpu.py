@@ -85,14 +85,22 @@ def test_batchnorm_train_forward_backward(shape, relu, res):
                                                        (2, 8, 8, 32, 8, 1, False), (2, 6, 6, 256, 512, 1, False),
                                                        # few-channel 3x3 layers with W % 16 == 0: the all-taps halo kernel (32/64 x 32/64 channels), ragged K splits
                                                        (2, 16, 16, 32, 32, 3, False), (1, 48, 32, 64, 32, 3, False), (3, 16, 48, 32, 64, 3, False),
-                                                       (1, 32, 16, 64, 64, 3, False), (2, 112, 112, 64, 64, 3, False)])
-def test_conv_weight_gradient(B, H, W, cin, cout, k, reflect):
-    """smirk_conv_wgrad_f32 (exact fp32 MFMA, split-K) against autograd's weight gradient"""
+                                                       (1, 32, 16, 64, 64, 3, False), (2, 112, 112, 64, 64, 3, False),
+                                                       # partial M / N tiles (MobileNetV3 widths), a K split that ends inside the last image
+                                                       (3, 7, 7, 40, 120, 1, False), (2, 14, 14, 160, 72, 1, False), (5, 5, 3, 24, 200, 3, False)])
+@pytest.mark.parametrize("mode", [2, 1, 0])
+def test_conv_weight_gradient(B, H, W, cin, cout, k, reflect, mode):
+    """smirk_conv_wgrad_f32 against autograd's weight gradient: split-fp16 x3 on the fp16 matrix pipe with LDS transpose reads (mode 2 = the default, 1 = one
+    chunk per barrier) and the exact-fp32 MFMA kernels (mode 0); generic split-K tiles and the all-taps halo kernels, ragged K splits, partial M / N tiles"""
     T, ops = _ops()
     g = _gen(H * cin + cout)
     xs, x64 = _act(torch.randn(B, H, W, cin, generator=g))
     ds, d64 = _act(torch.randn(B, H, W, cout, generator=g))
-    dw = ops.wgrad(ds, xs, B, H, W, cout, cin, k, reflect=reflect)
+    ops.lib.smirk_conv_wgrad_set_mode(mode)
+    try:
+        dw = ops.wgrad(ds, xs, B, H, W, cout, cin, k, reflect=reflect)
+    finally:
+        ops.lib.smirk_conv_wgrad_set_mode(-1)
     w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
     xin = F.pad(x64, (1, 1, 1, 1), mode="reflect") if reflect else x64
     F.conv2d(xin, w, padding=0 if (reflect or k == 1) else 1).backward(d64)
