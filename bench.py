@@ -546,8 +546,9 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
         return None
     dom = max(per, key=lambda k: per[k][2])
     fl, by, tm, n = per[dom]
-    split = ",true," in dom or dom.endswith("true>") or dom.startswith("conv_pp_kernel")      # split-fp16 (f16x3) kernels
-    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd", "wgrad_kernel"))   # wgrad: exact-fp32 MFMA
+    split = ",true," in dom or dom.endswith("true>") or dom.startswith("conv_pp_kernel") or "_f16_kernel" in dom      # split-fp16 (f16x3) kernels
+    # wgrad_kernel / wgrad3x3_halo_kernel: exact-fp32 MFMA; wgrad_f16_kernel / wgrad3x3_halo_f16_kernel: split-fp16 x3 (LDS transpose reads)
+    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd", "wgrad_kernel", "wgrad_f16_kernel", "wgrad3x3_halo"))
     traffic = None
     if traffic_table:
         key = dom.split("[")[0]                                   # the profiler appends a "[tile,waves,stages]" tag to some names
@@ -692,8 +693,8 @@ def main():
             "metric": METRIC[args.workload] if not args.plumbing_test else "PLUMBING TEST (CPU stub of the path; not a measurement)",
             "value": value, "unit": "faces/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": ("f32-class throughout (reference config: bf16 autocast): convolutions and their data gradients as split-fp16 x3 MFMA with f32 accumulate, weight "
-                      "gradients exact f32 MFMA, BatchNorm statistics f64, FLAME / raster f32, Adam f32" if args.workload == "train64" else
+            "dtype": ("f32-class throughout (reference config: bf16 autocast): convolutions, their data gradients and their weight gradients as split-fp16 x3 MFMA "
+                      "with f32 accumulate (depthwise / stem weight gradients f32 VALU), BatchNorm statistics f64, FLAME / raster f32, Adam f32" if args.workload == "train64" else
                       "f32 results; encoder + generator convs as split-fp16 x3 MFMA with f32 accumulate (fp32-class error), FLAME / raster f32"
                       if gen_prec == "f16x3" or args.workload == "infer256" else "f32"),
             "data": "synthetic",
