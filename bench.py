@@ -72,6 +72,8 @@ def parse_args(argv=None):
                          "layers = two full rounds of the 256 CUs, likewise 4 / 8 rounds at 28x28 / 56x56 — else the per-GPU batch)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run each micro-batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
+    ap.add_argument("--no-train-graphs", dest="train_graphs", action="store_false",
+                    help="train64: launch the two CNNs' forward / backward kernel by kernel from Python instead of replaying their HIP graphs")
     ap.add_argument("--generator-streams", type=int, default=1, help="generator stages of consecutive micro-batches alternate over this many streams")
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
@@ -486,12 +488,17 @@ class TrainWorkload(Workload):
         self.opt_g = torch.optim.Adam(self.gen_params, lr=1e-3)
         self.world = world
         self.buckets = 0
+        self.gen_step, self.enc_step = gen, enc
+        self.graphs = bool(getattr(args, "train_graphs", True))
+        if self.graphs:                                              # forward + backward of both CNNs as four HIP graphs (smirk_amd/cycle.py)
+            from smirk_amd.cycle import graph_cycle_modules
+            self.gen_step, self.enc_step = graph_cycle_modules(gen, enc, torch.zeros(B, 6, 224, 224, device=dev), torch.zeros(B, 3, 224, 224, device=dev))
 
     def step(self):
         import torch
         from smirk_amd.cycle import allreduce_gradients, cycle_forward, render_second_path
         rendered, masked = render_second_path(self.flame, self.rend, self.enc_out, self.feats, self.img, self.mask, self.face_prob, self.MK)
-        loss, recon, rf = cycle_forward(self.gen, self.enc, rendered, masked, self.feats)
+        loss, recon, rf = cycle_forward(self.gen_step, self.enc_step, rendered, masked, self.feats)
         fo = self.flame.forward(rf)                                  # smirk_trainer.py:299-300 (feeds the visualisation grid only)
         self.rend.forward(fo['vertices'], rf['cam'])
         self.opt_e.zero_grad(set_to_none=True); self.opt_g.zero_grad(set_to_none=True)
@@ -501,7 +508,14 @@ class TrainWorkload(Workload):
         self.opt_e.step(); self.opt_g.step()
         self.last = {"reconstructed_img": recon.detach(), "loss": loss.detach().reshape(1)}
 
-    instrumented = step
+    def instrumented(self):
+        """the launch profiler sees launches, not graph replays: the instrumented pass runs the same step kernel by kernel"""
+        g, e = self.gen_step, self.enc_step
+        self.gen_step, self.enc_step = self.gen, self.enc
+        try:
+            self.step()
+        finally:
+            self.gen_step, self.enc_step = g, e
 
 
 class PlumbingWorkload(Workload):
@@ -713,7 +727,11 @@ def main():
                        **({"masking": "given masked image" if args.given_masked else
                            "utils/masking.py stage on GPU (mesh-based point sampling + masking) from a synthetic hull mask",
                            "schedule": (f"software pipeline: generator(micro-batch i) on {args.generator_streams} stream(s) || encode+FLAME+render(micro-batch i+1)" if args.overlap else "serial stages")}
-                          if args.workload == "full" else {})},
+                          if args.workload == "full" else
+                          {"schedule": ("forward + backward of the two CNNs replayed from four HIP graphs (torch.cuda.make_graphed_callables over the HIP autograd "
+                                        "functions); FLAME / renderer / masking / loss / clip / Adam launched eagerly; roofline pass kernel by kernel"
+                                        if getattr(wl, "graphs", False) else "every kernel launched from Python (ctypes)")}
+                          if args.workload == "train64" else {})},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "path_tflops_per_gpu": value / world * flop_face / 1e12,
             "path_frac_of_f16_mfma_peak": value / world * flop_face / PEAK_F16_MFMA,

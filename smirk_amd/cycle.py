@@ -65,6 +65,53 @@ def cycle_forward(generator, encoder, rendered, masked, flame_feats, freeze_gene
     return cycle_loss(feats, flame_feats, use_eyelids, freeze_generator), recon, feats
 
 
+CYCLE_GRAD_KEYS = ("expression_params", "jaw_params", "eyelid_params", "shape_params")        # what cycle_loss differentiates (smirk_trainer.py:304-313)
+
+
+class _CycleEncoder(torch.nn.Module):
+    """SmirkEncoder as the cycle path uses it: the parameters the cycle loss does not touch (pose, camera — smirk_trainer.py:304-313 has no term for them)
+    leave detached, so a captured backward graph contains no backward pass of the (frozen) pose backbone — exactly what eager autograd prunes at run time."""
+
+    def __init__(self, encoder, grad_keys=CYCLE_GRAD_KEYS):
+        super().__init__()
+        self.encoder, self.grad_keys = encoder, tuple(grad_keys)
+
+    def forward(self, img):
+        out = self.encoder(img)
+        return {k: (v if k in self.grad_keys else v.detach()) for k, v in out.items()}
+
+
+class _CycleGenerator(torch.nn.Module):
+    """pass-through wrapper: make_graphed_callables patches the `forward` of the module it is given — the user's SmirkGenerator stays as it is"""
+
+    def __init__(self, generator):
+        super().__init__()
+        self.generator = generator
+
+    def forward(self, x):
+        return self.generator(x)
+
+
+def graph_cycle_modules(generator, encoder, generator_input, encoder_input, grad_keys=CYCLE_GRAD_KEYS, warmup=3):
+    """TRAIN-mode forward AND backward of the two CNNs captured into HIP graphs (`torch.cuda.make_graphed_callables`): the cycle step launches ~1300
+    kernels whose Python/ctypes enqueue (~40 ms) is as long as their execution on one MI355X; replaying four graphs (generator / encoder, forward /
+    backward) costs the host well under a millisecond each.  Everything the two `torch.autograd.Function`s do is stream-ordered device work on the
+    current stream (kernel launches of libsmirk_hip.so, allocator calls, no host synchronisation), which is what makes them capturable; BatchNorm running
+    statistics and `num_batches_tracked` are updated by captured kernels, parameters are read in place, so optimiser steps between replays are seen.
+    The sample tensors fix the shapes: `generator_input` [B, 6, H, W] (no gradient needed, as in smirk_trainer.py:293), `encoder_input` [B, 3, H, W].
+    Returns (generator_for_cycle, encoder_for_cycle): wrappers to call exactly like the modules (same shapes as the samples); the modules themselves are
+    left untouched and keep launching kernel by kernel.
+    Note: capturing runs the modules `warmup` + 1 times, which advances BatchNorm running statistics like that many training steps."""
+    if not (generator.training and encoder.training):
+        raise ValueError("graph_cycle_modules captures the TRAIN-mode path: call .train() first")
+    enc = _CycleEncoder(encoder, grad_keys)
+    gen = _CycleGenerator(generator)
+    enc.train(); gen.train()
+    gi = generator_input.detach().clone()
+    ei = encoder_input.detach().clone().requires_grad_(True)
+    return torch.cuda.make_graphed_callables((gen, enc), ((gi,), (ei,)), num_warmup_iters=warmup, allow_unused_input=True)
+
+
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True):
     """Data-parallel gradient exchange (C2): flatten the gradients into few large buckets, one all-reduce each (RCCL over xGMI on GPUs, gloo in the
     CPU tests), scatter back.  Parameters without a gradient on this rank are skipped on EVERY rank only if they are skipped everywhere — the trainer
