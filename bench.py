@@ -8,8 +8,8 @@ already started it under torch.distributed.run (RANK / WORLD_SIZE set) it just j
 
 Workloads (BASELINE.json configs):
   full      config 4 — full inference incl. SmirkGenerator re-synthesis on a 1024-frame batch: the batch is sharded in contiguous slices
-            over the N ranks (strong scaling: 1024 frames per step in total, whatever N is), every rank walks its shard in micro-batches of
-            128 frames, and the outputs (vertices + rendered + re-synthesised image) are all-gathered with RCCL, asynchronously, so that the
+            over the N ranks (strong scaling: 1024 frames per step in total, whatever N is), every rank runs its shard in one pass (or in
+            `--micro-batch` sized passes), and the outputs (vertices + rendered + re-synthesised image) are all-gathered with RCCL, asynchronously, so that the
             gather of one micro-batch overlaps the compute of the next.  `--batch B` instead fixes B frames PER GPU (weak scaling).
   infer256  config 3 — encoder + FLAME + renderer, 256 frames.
   flame512  config 2 — FLAME only, 512 random parameter vectors -> 5023 vertices.
@@ -48,8 +48,9 @@ FLOP_PER_FACE_TRAIN = 3 * 27.826e9 + 0.929e9 + 3 * 0.41e9 + 3 * 14.7e6
 PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA = 2500e12          # MI355X_MICROARCH.md: bf16/fp16 dense MFMA peak (the f16x3 kernel issues 3 MFMA-flop per algorithmic flop)
 PEAK_HBM = 8.0e12
-MICRO_BATCH = 167                # frames per pass of the path: fills whole rounds of 256-row x 128-column tiles on 256 CUs at the 14^2 / 28^2 / 56^2
-                                 # layers (activations ~11 GB per pass; 32-bit buffer offsets stay valid up to 325 frames)
+MICRO_BATCH = 1024               # frames per pass of the path = a rank's whole shard: 288 GB of HBM hold the 1024-frame job's ~64 GB of activations, and one big
+                                 # pass beats several tile-quantisation-tuned ones (profiles/r02z_microbatch_sweep.txt: 167 -> 7494, 334 -> 7709, 512 -> 7741-7769,
+                                 # 1024 -> 7816 faces/s; 167 = whole rounds of tiles at 14^2 / 28^2 / 56^2 but six passes + a 22-frame tail)
 METRIC = {"full": "faces/sec (encode+FLAME+render+generate) @224x224",
           "infer256": "faces/sec (encode+FLAME+render) @224x224",
           "flame512": "faces/sec (FLAME-only: shape,exp,pose,jaw -> 5023 vertices)",
@@ -68,12 +69,13 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=None, help="frames per step over ALL GPUs (strong scaling; default 1024 / 256 / 512 by workload)")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (weak scaling; overrides --global-batch)")
     ap.add_argument("--micro-batch", type=int, default=None,
-                    help="frames per pass of the path (default: 167 when the per-GPU batch is larger — 167 x 196 / 256 x 4 = 511.4 tiles of the deep 14x14\n"
-                         "layers = two full rounds of the 256 CUs, likewise 4 / 8 rounds at 28x28 / 56x56 — else the per-GPU batch)")
+                    help="frames per pass of the path (default: the rank's whole shard, up to 1024 frames; smaller values walk the shard in several passes with\n"
+                         "the generator of pass i overlapping the front end of pass i+1)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run each micro-batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
-    ap.add_argument("--no-train-graphs", dest="train_graphs", action="store_false",
-                    help="train64: launch the two CNNs' forward / backward kernel by kernel from Python instead of replaying their HIP graphs")
+    ap.add_argument("--train-graphs", dest="train_graphs", action="store_true",
+                    help="train64: replay the two CNNs' forward / backward from HIP graphs instead of launching kernel by kernel (measured: host enqueue 43 -> 27 ms "
+                         "per step, but the replay of ~1300 chained kernel nodes runs 3.8 ms slower on the GPU, which is the bound: 53.1 vs 49.4 ms)")
     ap.add_argument("--generator-streams", type=int, default=1, help="generator stages of consecutive micro-batches alternate over this many streams")
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
@@ -489,7 +491,7 @@ class TrainWorkload(Workload):
         self.world = world
         self.buckets = 0
         self.gen_step, self.enc_step = gen, enc
-        self.graphs = bool(getattr(args, "train_graphs", True))
+        self.graphs = bool(getattr(args, "train_graphs", False))
         if self.graphs:                                              # forward + backward of both CNNs as four HIP graphs (smirk_amd/cycle.py)
             from smirk_amd.cycle import graph_cycle_modules
             self.gen_step, self.enc_step = graph_cycle_modules(gen, enc, torch.zeros(B, 6, 224, 224, device=dev), torch.zeros(B, 3, 224, 224, device=dev))

@@ -109,7 +109,20 @@ __device__ __forceinline__ bool stage2_sum(const double* __restrict__ part, int 
     const int j = threadIdx.x >> 4, cl = threadIdx.x & 15;
     double sa = 0.0, sb = 0.0;
     if (c < C)
-        for (int k = j; k < nblocks; k += 16) { sa += part[((size_t)k * C + c) * 2]; sb += part[((size_t)k * C + c) * 2 + 1]; }
+        // eight partials are loaded before the first is added (same addition order): the rolled loop waited for every load before issuing the next one —
+        // 32 dependent L2 round trips, 13 us for a kernel with microseconds of work, 279 times per training step
+        for (int k0 = j; k0 < nblocks; k0 += 16 * 8) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 16 * u;
+                const bool on = k < nblocks;
+                va[u] = on ? part[((size_t)k * C + c) * 2] : 0.0;
+                vb[u] = on ? part[((size_t)k * C + c) * 2 + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sa += va[u]; sb += vb[u]; }
+        }
     red[j][cl][0] = sa; red[j][cl][1] = sb;
     __syncthreads();
     if (j != 0 || c >= C) return false;

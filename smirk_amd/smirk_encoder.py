@@ -368,7 +368,10 @@ class SmirkEncoder(nn.Module):
         outputs = {}
         if not img.is_cuda:
             raise L.SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
-        if os.environ.get("SMIRK_ENCODER_SERIAL") or self.training:   # profiling aid / training (one autograd graph, one stream): reference order
+        # SMIRK_ENCODER_SERIAL: profiling aid (reference order on one stream).  Training uses the three streams as well unless SMIRK_ENCODER_TRAIN_SERIAL is
+        # set: autograd runs every backward node on the stream its forward ran on and orders the streams itself, so the backbones' backward passes
+        # interleave exactly like their forward passes (their ~1000 launches per step are small and latency-bound one after the other).
+        if os.environ.get("SMIRK_ENCODER_SERIAL") or (self.training and os.environ.get("SMIRK_ENCODER_TRAIN_SERIAL")):
             for enc in (self.pose_encoder, self.shape_encoder, self.expression_encoder):
                 outputs.update(enc(img))
             return outputs

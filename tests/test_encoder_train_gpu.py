@@ -100,3 +100,35 @@ def test_encoder_train_then_eval_uses_the_updated_running_statistics():
         r = ref(img.cpu())
     for k in r:
         assert (o2[k].cpu() - r[k]).abs().max().item() < 2e-3, k
+
+
+def test_encoder_train_three_streams_equal_serial(monkeypatch):
+    """TRAIN-mode SmirkEncoder.forward forks the three backbones onto three HIP streams (smirk_amd/smirk_encoder.py) and autograd runs each backward on
+    its forward's stream: outputs, image gradient and parameter gradients must be those of the one-stream order, bit for bit, repeatedly."""
+    from smirk_amd import SmirkEncoder
+    esd = M.synth_encoder_state_dict()
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(3, 3, 96, 96, generator=g).cuda()
+    tgt = {"expression_params": torch.randn(3, 50, generator=g), "jaw_params": torch.rand(3, 3, generator=g) * 0.2,
+           "eyelid_params": torch.rand(3, 2, generator=g), "shape_params": torch.randn(3, 300, generator=g)}
+
+    def run():
+        enc = SmirkEncoder(); enc.load_state_dict(esd); enc = enc.cuda().train()
+        for p in enc.pose_encoder.parameters():
+            p.requires_grad_(False)
+        x = img.clone().requires_grad_(True)
+        out = enc(x)
+        _loss(out, tgt).backward()
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in out.items()}, x.grad.clone(),
+                {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}, {k: b.clone() for k, b in enc.named_buffers()})
+
+    monkeypatch.setenv("SMIRK_ENCODER_TRAIN_SERIAL", "1")
+    ref = run()
+    monkeypatch.delenv("SMIRK_ENCODER_TRAIN_SERIAL")
+    for _ in range(3):
+        got = run()
+        assert all(torch.equal(ref[0][k], got[0][k]) for k in ref[0])
+        assert torch.equal(ref[1], got[1])
+        assert ref[2].keys() == got[2].keys() and all(torch.equal(ref[2][k], got[2][k]) for k in ref[2])
+        assert all(torch.equal(ref[3][k], got[3][k]) for k in ref[3])
