@@ -620,8 +620,38 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
                                const float* shift, void* out, hipStream_t st, const float* fw, const float* fb, float* fout,
                                int fcout);
 
+static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                             const float* shift, const void* residual, void* out, void* stream, bool split);
+
+// The buffer-addressed operand DMA of the 3x3 split-fp16 kernels (32-bit per-lane offsets, out-of-range rows as the zero padding) needs every
+// input tensor below 2 GiB.  A whole 1024-frame shard in one pass exceeds that on the 224^2 / 112^2 layers (6.6 / 3.3 GB): such a layer is
+// launched as a few batch chunks that each fit — frames are independent and a frame's result does not depend on the batch it travels in
+// (tests/test_scale_gpu.py), so this is the same computation, and each chunk still holds >= 10^4 tiles.  Returns the images per launch.
+static int conv_batch_chunk(const SmirkConvDesc* d, bool split) {
+    if (!split || d->KH != 3 || d->B <= 1) return d->B;
+    const long long px = (long long)d->H * d->W, per = 4 * px * (d->C0 > d->C1 ? d->C0 : d->C1), lim = (1ll << 31) - 1;
+    if (per * d->B <= lim || per > lim) return d->B;
+    return (int)(lim / per);
+}
+
 static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                          const float* shift, const void* residual, void* out, void* stream, bool split) {
+    if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
+    const int bc = (d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0) ? conv_batch_chunk(d, split) : d->B;
+    if (bc >= d->B) return conv_dispatch_one(d, in0, in1, w, scale, shift, residual, out, stream, split);
+    const size_t ipx = (size_t)d->H * d->W, opx = (size_t)d->Ho * d->Wo * (d->out_mode == SMIRK_OUT_CONVT2X2 ? 4 : 1);
+    for (int b0 = 0; b0 < d->B; b0 += bc) {
+        SmirkConvDesc dc = *d;
+        dc.B = d->B - b0 < bc ? d->B - b0 : bc;
+        const int rc = conv_dispatch_one(&dc, (const float*)in0 + b0 * ipx * d->C0, in1 ? (const float*)in1 + b0 * ipx * d->C1 : nullptr, w, scale, shift,
+                                         residual ? (const float*)residual + b0 * opx * d->Cout : nullptr, (float*)out + b0 * opx * d->Cout, stream, split);
+        if (rc != SMIRK_OK) return rc;
+    }
+    return SMIRK_OK;
+}
+
+static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
+                             const float* shift, const void* residual, void* out, void* stream, bool split) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
     const int cq = split ? 8 : 4;                               // channel granule: one 16-byte vector (fp32) / one hi+lo group
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->C0 <= 0 || d->C0 % cq || d->C1 % cq || d->C1 < 0 ||
@@ -676,7 +706,17 @@ extern "C" int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0,
     if (!d || !in0 || !w || !fw || !out_nchw || fcout <= 0 || fcout > 4 || d->Cout != 32) return SMIRK_ERR_BAD_ARG;
     if (d->C0 % 8 || d->C1 % 8 || (d->C1 > 0 && !in1) || d->act != SMIRK_ACT_RELU) return SMIRK_ERR_BAD_ARG;
     if (!smirk_conv3x3_patch_eligible(d, false)) return SMIRK_ERR_UNSUPPORTED;
-    return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, nullptr, (hipStream_t)stream, fw, fb, out_nchw, fcout);
+    const int bc = (d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0) ? conv_batch_chunk(d, true) : d->B;
+    if (bc >= d->B) return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, nullptr, (hipStream_t)stream, fw, fb, out_nchw, fcout);
+    const size_t px = (size_t)d->H * d->W;
+    for (int b0 = 0; b0 < d->B; b0 += bc) {                     // batch chunks below 2 GiB each (see conv_batch_chunk)
+        SmirkConvDesc dc = *d;
+        dc.B = d->B - b0 < bc ? d->B - b0 : bc;
+        const int rc = smirk_conv3x3_patch_launch(&dc, (const float*)in0 + b0 * px * d->C0, in1 ? (const float*)in1 + b0 * px * d->C1 : nullptr, w, scale, shift,
+                                                  nullptr, (hipStream_t)stream, fw, fb, out_nchw + b0 * px * fcout, fcout);
+        if (rc != SMIRK_OK) return rc;
+    }
+    return SMIRK_OK;
 }
 
 extern "C" int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
