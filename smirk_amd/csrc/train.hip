@@ -505,28 +505,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
     int fy, fx;
     { const int rem = (int)(p0 - (long long)fb * a.W * a.H); fy = rem / a.W; fx = rem - fy * a.W; }
     int fc = 0;
-    uint4 ra[SUB][2], rb[SUB][2];
+    // Operand fetch through buffer resources with running 32-bit offsets (both tensors are < 2 GiB here, the dispatcher checks): NHWC pixels are linear in
+    // memory, so chunk c's dz piece sits 16 pixels after chunk c-1's, and (zero padding) the x pixel under this thread's tap is the linear pixel
+    // p + (ky - pad) * W + (kx - pad) whenever it lies inside the image — one add per chunk instead of a 64-bit multiply chain; a lane with nothing to fetch
+    // (past the split / the tensor, tap outside the image, column beyond N) carries an out-of-range offset and the load returns zeros: no branches, no zero
+    // fill.  (PMC of the pointer-based first version: 8.8 VALU + 3.2 SALU instructions per MFMA, the VALU pipe as busy as the matrix pipe.)  Reflection
+    // padding (three 14x14 layers) computes its source pixel explicitly.
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, (short)0, (int)(npix * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)(npix * a.Cin * 4), 0x00020000);
+    const unsigned OOB = 0x80000000u;
+    unsigned oa = (unsigned)(((unsigned long long)p0 * Gout + gco) * 32ull);
+    unsigned ob = (unsigned)(((long long)p0 + (long long)(ky - a.pad) * a.W + (kx - a.pad)) * Gin + gci) * 32u;
+    const unsigned a_step = (unsigned)(WG_KC * Gout * 32), b_step = (unsigned)(WG_KC * Gin * 32);
+    u32x4_t ra[SUB][2], rb[SUB][2];
     auto fetch = [&]() {
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
-            ra[s][0] = ra[s][1] = rb[s][0] = rb[s][1] = make_uint4(0u, 0u, 0u, 0u);
-            if (fc < a.chunks_per_split && fb < a.B) {
-                if (a_on) {
-                    const uint4* q = (const uint4*)(a.dz + ((size_t)(p0 + (long long)fc * WG_KC) * Gout + gco) * 8);
-                    ra[s][0] = q[0]; ra[s][1] = q[1];
-                }
-                if (b_on) {
-                    int iy = fy + ky - a.pad, ix = fx + kx - a.pad;
-                    bool ok = true;
-                    if (a.reflect) { iy = reflect_idx(iy, a.H); ix = reflect_idx(ix, a.W); }
-                    else ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                    if (ok) {
-                        const uint4* q = (const uint4*)(a.x + ((((size_t)fb * a.H + iy) * a.W + ix) * Gin + gci) * 8);
-                        rb[s][0] = q[0]; rb[s][1] = q[1];
-                    }
-                }
-            }
+            const bool live = fc < a.chunks_per_split && fb < a.B;
+            const unsigned va = (live && a_on) ? oa : OOB;
+            ra[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va, 0, 0);
+            ra[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va, 16, 0);
+            const int iy = fy + ky - a.pad, ix = fx + kx - a.pad;
+            unsigned vb;
+            if (a.reflect) vb = (live && b_on) ? (unsigned)((((fb * a.H + reflect_idx(iy, a.H)) * a.W + reflect_idx(ix, a.W)) * Gin + gci) * 32) : OOB;
+            else vb = (live && b_on && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? ob : OOB;
+            rb[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rsb, vb, 0, 0);
+            rb[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rsb, vb, 16, 0);
             ++fc;
+            oa += a_step; ob += b_step;
             fx += WG_KC;
             while (fx >= a.W) { fx -= a.W; if (++fy == a.H) { fy = 0; ++fb; } }
         }
@@ -550,8 +557,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
         const int buf = it & 1;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
-            if (sg < GA) { *(uint4*)(As[buf][s] + wa_hi) = ra[s][0]; *(uint4*)(As[buf][s] + wa_lo) = ra[s][1]; }
-            *(uint4*)(Bs[buf][s] + wb_hi) = rb[s][0]; *(uint4*)(Bs[buf][s] + wb_lo) = rb[s][1];
+            if (sg < GA) { *(u32x4_t*)(As[buf][s] + wa_hi) = ra[s][0]; *(u32x4_t*)(As[buf][s] + wa_lo) = ra[s][1]; }
+            *(u32x4_t*)(Bs[buf][s] + wb_hi) = rb[s][0]; *(u32x4_t*)(Bs[buf][s] + wb_lo) = rb[s][1];
         }
         __syncthreads();                       // this stage visible; the stage written next iteration was last read two iterations ago, behind this barrier
         if (it + 1 < iters) fetch();
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(WgradArgs a) {
 // pixel quads][CIN channels].  The B fragment of tap (ky, kx) for chunk pixel k is halo pixel ky*18 + kx + k: a per-lane constant added to the pixel index, so
 // the shifted fragments of all nine taps are read from the ONE staged halo (adding 4 to a pixel index moves exactly one pixel quad, hence the second transpose
 // read of an operand is again +256 bytes).  The (TM/32) x 9 x (CIN/32) MFMA blocks are dealt round-robin to NW waves; a wave's A fragments are read once per chunk.
-template <int TM, int CIN, int NW, int SUB>
+template <int TM, int CIN, int NW, int SUB, bool BUF>
 __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a, int trmap) {
     constexpr int NT = NW * 64, HPX = 54, HQ = 14;
     constexpr int MB = TM / 32, NBQ = CIN / 32;                               // 32-channel quads of A and B
@@ -720,14 +727,68 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
     int fy, fxc;
     { const int rem = (int)(ch0 - (long long)fb * cpr * a.H); fy = rem / cpr; fxc = rem - fy * cpr; }
     int fc = 0;
-    uint4 ra[SUB][NLA][2], rb[SUB][NLB][2];
-    auto fetch = [&]() {
+    // Operand fetch through buffer resources with running 32-bit offsets (see wgrad_f16_kernel): W % 16 == 0, so consecutive chunks are consecutive runs of 16
+    // pixels in memory — across row ends and image ends too — and a chunk's operands sit at (first pixel of the chunk) + a per-thread constant; halo pixels
+    // outside the image and idle lanes carry an out-of-range offset (zeros).
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const long long npix = (long long)a.B * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, (short)0, (int)(npix * TM * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)(npix * CIN * 4), 0x00020000);
+    const unsigned OOB = 0x80000000u;
+    unsigned ca[NLA];                                   // per-thread constant part of the dz offset: (pixel k of the chunk, group g)
+    int cbo[NLB], chy[NLB], chx[NLB];                   // x halo: offset relative to the chunk's first pixel, halo row / column
+#pragma unroll
+    for (int u = 0; u < NLA; ++u) {
+        const int e = tid + u * NT;
+        ca[u] = e < 16 * GA ? (unsigned)(e * 32) : OOB;                        // (k * GA + g) * 32 with e = k * GA + g
+    }
+#pragma unroll
+    for (int u = 0; u < NLB; ++u) {
+        const int e = tid + u * NT, hp = e / GB, g = e % GB;
+        chy[u] = e < HPX * GB ? hp / 18 : -100000;                             // idle lane: a row no image has
+        chx[u] = hp % 18;
+        cbo[u] = (((chy[u] - 1) * a.W + chx[u] - 1) * GB + g) * 32;
+    }
+    unsigned pa = (unsigned)(ch0 * 16 * GA * 32), pb = (unsigned)(ch0 * 16 * GB * 32);     // byte offset of the next chunk's first pixel in dz / x
+    u32x4_t ra[SUB][NLA][2], rb[SUB][NLB][2];
+    auto fetch_buf = [&]() {
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            const bool live = fc < a.chunks_per_split && fb < a.B;
+            const int x0 = fxc * 16;
+            // waves whose 64 items all lie past the end of the list skip the instruction (wave-uniform test): with 6-12 waves and 64-432 items most waves
+            // have nothing to fetch, and an all-out-of-range load still costs its issue slot in the memory pipeline
+#pragma unroll
+            for (int u = 0; u < NLA; ++u) {
+                if (__builtin_amdgcn_readfirstlane(wave * 64 + u * NT) < 16 * GA) {
+                    const unsigned va = (live && ca[u] != OOB) ? pa + ca[u] : OOB;
+                    ra[s][u][0] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va, 0, 0);
+                    ra[s][u][1] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va, 16, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) {
+                if (__builtin_amdgcn_readfirstlane(wave * 64 + u * NT) < HPX * GB) {
+                    const bool ok = live && (unsigned)(fy - 1 + chy[u]) < (unsigned)a.H && (unsigned)(x0 - 1 + chx[u]) < (unsigned)a.W;
+                    const unsigned vb = ok ? pb + (unsigned)cbo[u] : OOB;
+                    rb[s][u][0] = __builtin_amdgcn_raw_buffer_load_b128(rsb, vb, 0, 0);
+                    rb[s][u][1] = __builtin_amdgcn_raw_buffer_load_b128(rsb, vb, 16, 0);
+                }
+            }
+            ++fc;
+            pa += 16 * GA * 32; pb += 16 * GB * 32;
+            if (++fxc == cpr) { fxc = 0; if (++fy == a.H) { fy = 0; ++fb; } }
+        }
+    };
+    // pointer-based variant (64-bit addresses, exec-masked loads): measured FASTER than the buffer form for the 6- and 12-wave instantiations (64x32: 120 vs 95-103
+    // TFLOP/s, 32x64: 134 vs 102-119, 64x64: 204 vs 193-202) and slower for the 3-wave 32x32 one (121 vs 145-154), same box — BUF selects per instantiation
+    auto fetch_ptr = [&]() {
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
 #pragma unroll
-            for (int u = 0; u < NLA; ++u) ra[s][u][0] = ra[s][u][1] = make_uint4(0u, 0u, 0u, 0u);
+            for (int u = 0; u < NLA; ++u) ra[s][u][0] = ra[s][u][1] = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int u = 0; u < NLB; ++u) rb[s][u][0] = rb[s][u][1] = make_uint4(0u, 0u, 0u, 0u);
+            for (int u = 0; u < NLB; ++u) rb[s][u][0] = rb[s][u][1] = u32x4_t{0u, 0u, 0u, 0u};
             if (fc < a.chunks_per_split && fb < a.B) {
                 const int x0 = fxc * 16;
 #pragma unroll
@@ -735,7 +796,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
                     const int e = tid + u * NT;
                     if (e < 16 * GA) {
                         const int k = e / GA, g = e % GA;
-                        const uint4* q = (const uint4*)(a.dz + ((((size_t)fb * a.H + fy) * a.W + x0 + k) * GA + g) * 8);
+                        const u32x4_t* q = (const u32x4_t*)(a.dz + ((((size_t)fb * a.H + fy) * a.W + x0 + k) * GA + g) * 8);
                         ra[s][u][0] = q[0]; ra[s][u][1] = q[1];
                     }
                 }
@@ -746,7 +807,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
                         const int hp = e / GB, g = e % GB, hy = hp / 18, hx = hp % 18;
                         const int iy = fy - 1 + hy, ix = x0 - 1 + hx;
                         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                            const uint4* q = (const uint4*)(a.x + ((((size_t)fb * a.H + iy) * a.W + ix) * GB + g) * 8);
+                            const u32x4_t* q = (const u32x4_t*)(a.x + ((((size_t)fb * a.H + iy) * a.W + ix) * GB + g) * 8);
                             rb[s][u][0] = q[0]; rb[s][u][1] = q[1];
                         }
                     }
@@ -756,6 +817,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
             if (++fxc == cpr) { fxc = 0; if (++fy == a.H) { fy = 0; ++fb; } }
         }
     };
+    auto fetch = [&]() { if constexpr (BUF) fetch_buf(); else fetch_ptr(); };
     // transpose-read lane geometry (see wgrad_f16_kernel)
     const int li = lane & 15, r4 = trmap ? (li & 3) : (li >> 2), q4 = trmap ? (li >> 2) : (li & 3);
     const int gl = ((lane >> 4) & 1) * 2 + (q4 >> 1), khalf = lane >> 5;
@@ -779,8 +841,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
                 const int e = tid + u * NT;
                 if (e < 16 * GA) {
                     const int k = e / GA, g = e % GA;
-                    *(uint4*)(As[buf][s] + wgf_slot(GA / 4, 4, 0, g, k) * 16) = ra[s][u][0];
-                    *(uint4*)(As[buf][s] + wgf_slot(GA / 4, 4, 1, g, k) * 16) = ra[s][u][1];
+                    *(u32x4_t*)(As[buf][s] + wgf_slot(GA / 4, 4, 0, g, k) * 16) = ra[s][u][0];
+                    *(u32x4_t*)(As[buf][s] + wgf_slot(GA / 4, 4, 1, g, k) * 16) = ra[s][u][1];
                 }
             }
 #pragma unroll
@@ -788,8 +850,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
                 const int e = tid + u * NT;
                 if (e < HPX * GB) {
                     const int hp = e / GB, g = e % GB;
-                    *(uint4*)(Bs[buf][s] + wgf_slot(GB / 4, HQ, 0, g, hp) * 16) = rb[s][u][0];
-                    *(uint4*)(Bs[buf][s] + wgf_slot(GB / 4, HQ, 1, g, hp) * 16) = rb[s][u][1];
+                    *(u32x4_t*)(Bs[buf][s] + wgf_slot(GB / 4, HQ, 0, g, hp) * 16) = rb[s][u][0];
+                    *(u32x4_t*)(Bs[buf][s] + wgf_slot(GB / 4, HQ, 1, g, hp) * 16) = rb[s][u][1];
                 }
             }
         }
@@ -1014,13 +1076,14 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
         h.chunks_per_split = (int)((chunks + nsplit - 1) / nsplit);          // W % 16 == 0: a 16-pixel chunk never crosses a row
         hipStream_t hs = (hipStream_t)stream;
         smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
-        const int mode = wgrad_f16_mode();
+        const bool fits32h = npix * Cout * 4 < (1ll << 31) && npix * Cin * 4 < (1ll << 31);     // 32-bit buffer offsets (see below)
+        const int mode = fits32h ? wgrad_f16_mode() : 0;
         if (mode) {                                                          // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
             const int trmap = (mode >> 4) & 1;
-            if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 32, 3, 2>), dim3(nsplit), dim3(192), 0, hs, h, trmap);
-            else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 32, 6, 2>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
-            else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 64, 6, 1>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
-            else SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 64, 12, 1>), dim3(nsplit), dim3(768), 0, hs, h, trmap);
+            if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 32, 3, 2, true>), dim3(nsplit), dim3(192), 0, hs, h, trmap);
+            else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 32, 6, 2, false>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
+            else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 64, 6, 1, false>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
+            else SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 64, 12, 1, false>), dim3(nsplit), dim3(768), 0, hs, h, trmap);
         } else if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 32>), dim3(nsplit), dim3(256), 0, hs, h);
         else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 32>), dim3(nsplit), dim3(256), 0, hs, h);
         else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 64>), dim3(nsplit), dim3(256), 0, hs, h);
@@ -1037,7 +1100,9 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const dim3 grid((Cout + TM - 1) / TM, (N + 127) / 128, nsplit);
     smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
-    const int mode = wgrad_f16_mode();
+    // the split-fp16 kernel fetches through buffer resources with 32-bit offsets: operands of 2 GiB and more take the exact-fp32 kernel (64-bit pointers)
+    const bool fits32 = npix * Cout * 4 < (1ll << 31) && npix * Cin * 4 < (1ll << 31);
+    const int mode = fits32 ? wgrad_f16_mode() : 0;
     if (mode) {                                                              // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
         const int trmap = (mode >> 4) & 1;
         if ((mode & 15) == 1) {

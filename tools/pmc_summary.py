@@ -11,7 +11,7 @@ def main(db, counter):
     rows = c.execute(f"select {name_col}, counter_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
     agg = {}
     for k, _, v in rows:
-        a = agg.setdefault(k.split("(")[0].replace("void ", ""), [0, 0.0])
+        a = agg.setdefault(k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], [0, 0.0])
         a[0] += 1; a[1] += float(v)
     for k, (n, s) in sorted(agg.items(), key=lambda t: -t[1][1]):
         print(f"{k[:80]:80s} {n:6d} {s / n:16.1f}")

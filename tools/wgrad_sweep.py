@@ -1,9 +1,10 @@
 """Per-layer timing of the convolution weight gradient (smirk_conv_wgrad_f32) at the train64 sizes.  The kernel family is chosen by $SMIRK_WGRAD_F16
-(read once per process): 0 = exact-fp32 MFMA, 1 / 2 = split-fp16 x3 with LDS transpose reads (1 / 2 chunks per barrier).  Usage: python tools/wgrad_sweep.py [B]"""
+(read once per process): 0 = exact-fp32 MFMA, 1 / 2 = split-fp16 x3 with LDS transpose reads (1 / 2 chunks per barrier).  Usage: python tools/wgrad_sweep.py [B [H,Cout,Cin,k]]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smirk_amd import _lib as L
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ONLY = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else None          # "H,Cout,Cin,k": one layer (PMC runs)
 lib = L.lib()
 st = L.stream_ptr()
 # (H, Cout, Cin, KH, reflect): SmirkGenerator layers (U-Net levels + bottleneck/res blocks + ConvT as 1x1 over space-to-depth) and two encoder pointwise shapes
@@ -14,6 +15,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 tot = 0.0
 print(f"SMIRK_WGRAD_F16={os.environ.get('SMIRK_WGRAD_F16', '(default)')} SMIRK_WGRAD_HALO={os.environ.get('SMIRK_WGRAD_HALO', '(default)')} B={B}")
 for H, co, ci, k, refl in layers:
+    if ONLY and (H, co, ci, k) != ONLY:
+        continue
     dz = torch.randn(B, H, H, co, device="cuda", generator=g).view(torch.float32)       # any bit pattern is a valid split16 tensor for timing
     x = torch.randn(B, H, H, ci, device="cuda", generator=g)
     dw = torch.empty(co, k * k * ci, device="cuda")
