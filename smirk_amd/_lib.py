@@ -130,6 +130,8 @@ _SIGS = {
     "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
     "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "smirk_bn_set_fused": (_i, [_i]),
+    "smirk_bn_fused_errors": (_i, []),
     "smirk_colsum_split16": (_i, [_p, _sz, _i, _p, _p, _sz, _p]),
     "smirk_maxpool2x2_backward_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_reflect_pad1_backward_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

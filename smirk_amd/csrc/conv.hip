@@ -623,12 +623,12 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
 static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                              const float* shift, const void* residual, void* out, void* stream, bool split);
 
-// The buffer-addressed operand DMA of the 3x3 split-fp16 kernels (32-bit per-lane offsets, out-of-range rows as the zero padding) needs every
+// The buffer-addressed operand DMA of the split-fp16 kernels (32-bit per-lane offsets, out-of-range rows as the zero padding) needs every
 // input tensor below 2 GiB.  A whole 1024-frame shard in one pass exceeds that on the 224^2 / 112^2 layers (6.6 / 3.3 GB): such a layer is
 // launched as a few batch chunks that each fit — frames are independent and a frame's result does not depend on the batch it travels in
 // (tests/test_scale_gpu.py), so this is the same computation, and each chunk still holds >= 10^4 tiles.  Returns the images per launch.
 static int conv_batch_chunk(const SmirkConvDesc* d, bool split) {
-    if (!split || d->KH != 3 || d->B <= 1) return d->B;
+    if (!split || d->B <= 1) return d->B;
     const long long px = (long long)d->H * d->W, per = 4 * px * (d->C0 > d->C1 ? d->C0 : d->C1), lim = (1ll << 31) - 1;
     if (per * d->B <= lim || per > lim) return d->B;
     return (int)(lim / per);

@@ -14,6 +14,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "conv_common.h"
 
 namespace {
@@ -46,11 +49,10 @@ inline unsigned blocks_for(size_t items, unsigned cap) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define RED_BLOCKS 512
 template <int MODE>
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
-                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                     double* __restrict__ part /*[blocks][C][2]*/) {
-    __shared__ double red[256 * 16];
+__device__ __forceinline__ void colsum_partial(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
+                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                               double* __restrict__ part /*[blocks][C][2]*/, double* red /*[256 * 16] in LDS*/) {
     const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;          // RPB rows in flight per block iteration; when G does not
     const bool active = rl < RPB;                                                   // divide 256 the last 256 - RPB*G threads only attend the barriers
     double s1[8], s2[8];
@@ -101,6 +103,14 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
         for (int r = 0; r < RPB; ++r) a += red[(r * G + gg) * 16 + k];
         part[((size_t)blockIdx.x * G * 8 + gg * 8 + (k >> 1)) * 2 + (k & 1)] = a;
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                     double* __restrict__ part /*[blocks][C][2]*/) {
+    __shared__ double red[256 * 16];
+    colsum_partial<MODE>(z, dy, M, G, mean, invstd, gamma, beta, relu, part, red);
 }
 
 // stage 2: the <= 512 per-block partials of a channel are summed by 16 threads (strided, fixed order) and combined in LDS in a fixed order;
@@ -159,9 +169,9 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ 
 // The two BatchNorm element-wise kernels give every thread a FIXED 8-channel group and let it walk rows (256 / G rows in flight per block), so
 // the per-channel coefficients are loaded once into registers and no per-element index division is needed.
 // y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ residual, int relu, float* __restrict__ y) {
+__device__ __forceinline__ void bn_apply_body(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
+                                              const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              const float* __restrict__ residual, int relu, float* __restrict__ y) {
     const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
     if (rl >= RPB) return;
     float mu[8], is[8], ga[8], be[8];
@@ -186,13 +196,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         store_group(y + i * 8, v);
     }
 }
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, int relu, float* __restrict__ y) {
+    bn_apply_body(z, M, G, mean, invstd, gamma, beta, residual, relu, y);
+}
 
 // dz = gamma * invstd * (dyh - sum_dyh / n - xhat * sum_dyh_xhat / n)
-__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
-                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
-                                                                float* __restrict__ dz) {
+__device__ __forceinline__ void bn_backward_apply_body(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
+                                                       float* __restrict__ dz) {
     const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
     if (rl >= RPB) return;
     float mu[8], is[8], ga[8], be[8], s1[8], s2[8];
@@ -213,6 +228,91 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
             v[q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
         }
         store_group(dz + i * 8, v);
+    }
+}
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
+                                                                float* __restrict__ dz) {
+    bn_backward_apply_body(z, dy, M, G, inv_n, mean, invstd, gamma, beta, sum_dy, sum_dy_xhat, relu, dz);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One-launch BatchNorm for tensors whose three passes are shorter than the gaps between three dependent launches (everything below ~64 MB: the
+// encoders' ~135 layers and the generator's 14^2 / 28^2 levels — 279 BatchNorm calls per training step whose finalisation kernels alone were 3.7 ms
+// of pure launch gap).  A grid of <= 256 co-resident workgroups runs the SAME three stages — partial sums (colsum_partial), finalisation of 16 channels
+// per workgroup (stage2_sum's fixed order), element-wise pass — separated by two grid barriers: an arrival counter in device memory, release / acquire
+// fences, a bounded spin (a grid that for any reason is not fully resident raises a sticky error word instead of hanging the GPU; smirk_bn_fused_errors).
+// Counters are library-owned, one set per stream, and reset by the last workgroup to leave, so back-to-back launches on a stream need no memset.
+// With <= 256 workgroups of 36 KB LDS, four such grids (the three encoder streams + the generator) fit on the 256 CUs simultaneously.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool grid_barrier(unsigned* cnt, unsigned target, int* flag_lds) {
+    __threadfence();                                        // release: this thread's global writes are visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int it = 0; it < (1 << 21); ++it) {
+            if (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *flag_lds = ok;
+    }
+    __syncthreads();
+    __threadfence();                                        // acquire: stale L1 lines are dropped before other workgroups' results are read
+    return *flag_lds != 0;
+}
+
+struct BnFusedArgs {
+    const float *z, *dy;                                    // dy: backward only
+    size_t M;
+    int G, relu;
+    const float *gamma, *beta, *residual;
+    float eps, momentum;
+    float *mean, *var, *invstd, *running_mean, *running_var;   // forward: written; backward: mean / invstd are read
+    float *out;                                             // y (forward) / dz (backward)
+    float *dgamma, *dbeta;
+    double* part;
+    unsigned* sync;                                         // [0], [1] barrier arrivals, [2] exit tickets, [3] sticky error word
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_fused_kernel(BnFusedArgs a) {
+    __shared__ double red[256 * 16];
+    __shared__ double red2[16][16][2];
+    __shared__ int flag;
+    const int C = a.G * 8, nb = gridDim.x;
+    colsum_partial<MODE>(a.z, a.dy, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.relu, a.part, red);
+    bool ok = grid_barrier(a.sync + 0, (unsigned)nb, &flag);
+    for (int c0 = blockIdx.x * 16; c0 < C; c0 += nb * 16) {  // workgroup-uniform trip count: stage2_sum contains a barrier
+        const int c = c0 + (threadIdx.x & 15);
+        double sa, sb;
+        if (stage2_sum(a.part, nb, C, c, sa, sb, red2)) {
+            if (MODE == 0) {
+                const double n = (double)a.M, m = sa / n;
+                double v = sb / n - m * m;
+                if (v < 0.0) v = 0.0;
+                a.mean[c] = (float)m; a.var[c] = (float)v; a.invstd[c] = (float)(1.0 / sqrt(v + (double)a.eps));
+                if (a.running_mean) a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+                if (a.running_var) a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
+            } else {
+                a.dbeta[c] = (float)sa; a.dgamma[c] = (float)sb;
+            }
+        }
+        __syncthreads();                                    // red2 is reused by the next channel slab
+    }
+    ok = grid_barrier(a.sync + 1, (unsigned)nb, &flag) && ok;
+    if (MODE == 0) bn_apply_body(a.z, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.residual, a.relu, a.out);
+    else bn_backward_apply_body(a.z, a.dy, a.M, a.G, (float)(1.0 / (double)a.M), a.mean, a.invstd, a.gamma, a.beta, a.dbeta, a.dgamma, a.relu, a.out);
+    if (threadIdx.x == 0) {
+        if (!ok) __hip_atomic_store(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every workgroup takes its exit ticket AFTER it has seen barrier 2 complete, so nobody is spinning on the counters when the last one clears them
+        if (__hip_atomic_fetch_add(a.sync + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1) {
+            __hip_atomic_store(a.sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 2, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -950,6 +1050,65 @@ extern "C" int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin
 
 extern "C" size_t smirk_train_reduce_workspace_bytes(int C) { return (size_t)RED_BLOCKS * (size_t)C * 2 * sizeof(double); }
 
+// ---- one-launch BatchNorm (bn_fused_kernel): library-owned barrier counters, one 64-byte set per stream -----------------------------------------
+#define BN_SYNC_SLOTS 256
+#define BN_FUSED_MAX_BYTES (64ll << 20)
+#define BN_FUSED_BLOCKS 256
+static std::mutex g_bn_mu;
+static unsigned* g_bn_pool = nullptr;
+static bool g_bn_pool_failed = false;
+static std::unordered_map<hipStream_t, int> g_bn_slots;
+static int g_bn_fused_override = -1;
+static bool bn_fused_enabled() {
+    static const int env = [] { const char* e = getenv("SMIRK_BN_FUSED"); return e ? atoi(e) : 1; }();
+    return (g_bn_fused_override >= 0 ? g_bn_fused_override : env) != 0;
+}
+// the stream's counter set, or nullptr when none can be had right now (first use while the stream is being captured into a graph: allocating would
+// invalidate the capture — the caller then takes the three-launch path, which computes the same thing)
+static unsigned* bn_sync_for(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_bn_mu);
+    if (g_bn_pool_failed) return nullptr;
+    if (!g_bn_pool) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+        unsigned* p = nullptr;
+        if (hipMalloc((void**)&p, BN_SYNC_SLOTS * 64) != hipSuccess || hipMemset(p, 0, BN_SYNC_SLOTS * 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            g_bn_pool_failed = true;
+            return nullptr;
+        }
+        g_bn_pool = p;
+    }
+    auto it = g_bn_slots.find(st);
+    if (it == g_bn_slots.end()) {
+        if (g_bn_slots.size() >= BN_SYNC_SLOTS) return nullptr;
+        it = g_bn_slots.emplace(st, (int)g_bn_slots.size()).first;
+    }
+    return g_bn_pool + it->second * 16;
+}
+extern "C" int smirk_bn_set_fused(int on) {
+    const int prev = bn_fused_enabled() ? 1 : 0;
+    g_bn_fused_override = on;
+    return prev;
+}
+// number of streams whose one-launch BatchNorm ever timed out in a grid barrier (0 = never; synchronises the device)
+extern "C" int smirk_bn_fused_errors(void) {
+    std::lock_guard<std::mutex> lk(g_bn_mu);
+    if (!g_bn_pool) return 0;
+    static unsigned host[BN_SYNC_SLOTS * 16];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, g_bn_pool, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return SMIRK_ERR_LAUNCH;
+    int n = 0;
+    for (int i = 0; i < BN_SYNC_SLOTS; ++i) n += host[i * 16 + 3] ? 1 : 0;
+    return n;
+}
+// grid of the one-launch form, or 0 when the tensor takes the three-launch path
+static unsigned bn_fused_grid(size_t M, int C) {
+    if (!bn_fused_enabled() || (long long)M * C * 4 > BN_FUSED_MAX_BYTES) return 0;
+    const int RPB = 256 / (C / 8);
+    const size_t rows = (M + RPB - 1) / RPB;
+    return (unsigned)(rows > BN_FUSED_BLOCKS ? BN_FUSED_BLOCKS : rows);
+}
+
 extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
                                               float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var,
                                               float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -957,6 +1116,17 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
+    if (const unsigned fg = bn_fused_grid(M, C)) {
+        if (unsigned* sync = bn_sync_for(st)) {
+            BnFusedArgs a;
+            a.z = (const float*)z; a.dy = nullptr; a.M = M; a.G = G; a.relu = relu; a.gamma = gamma; a.beta = beta; a.residual = (const float*)residual;
+            a.eps = eps; a.momentum = momentum; a.mean = save_mean; a.var = save_var; a.invstd = save_invstd; a.running_mean = running_mean;
+            a.running_var = running_var; a.out = (float*)y; a.dgamma = nullptr; a.dbeta = nullptr; a.part = (double*)ws; a.sync = sync;
+            smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 4 : 3));
+            SMIRK_LAUNCH(bn_fused_kernel<0>, dim3(fg), dim3(256), 0, st, a);
+            return smirk_launch_status();
+        }
+    }
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
@@ -977,6 +1147,17 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
+    if (const unsigned fg = bn_fused_grid(M, C)) {
+        if (unsigned* sync = bn_sync_for(st)) {
+            BnFusedArgs a;
+            a.z = (const float*)z; a.dy = (const float*)dy; a.M = M; a.G = G; a.relu = relu; a.gamma = gamma; a.beta = beta; a.residual = nullptr;
+            a.eps = 0.f; a.momentum = 0.f; a.mean = (float*)save_mean; a.var = nullptr; a.invstd = (float*)save_invstd; a.running_mean = nullptr;
+            a.running_var = nullptr; a.out = (float*)dz; a.dgamma = dgamma; a.dbeta = dbeta; a.part = (double*)ws; a.sync = sync;
+            smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 5);
+            SMIRK_LAUNCH(bn_fused_kernel<1>, dim3(fg), dim3(256), 0, st, a);
+            return smirk_launch_status();
+        }
+    }
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
