@@ -369,9 +369,9 @@ int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* 
 /* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
 int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
-/* Tensors up to 64 MB run forward / backward BatchNorm as ONE cooperative launch (partial sums, finalisation and the element-wise pass separated by grid
+/* Opt-in: tensors up to 64 MB can run forward / backward BatchNorm as ONE cooperative launch (partial sums, finalisation and the element-wise pass separated by grid
  * barriers; same arithmetic and summation order inside each stage as the three-launch form used above that size).  smirk_bn_set_fused(0 / 1 / -1) forces the
- * three-launch form / the one-launch form / $SMIRK_BN_FUSED (default on) and returns the previous setting; smirk_bn_fused_errors() synchronises the device and
+ * three-launch form / the one-launch form / $SMIRK_BN_FUSED (default OFF: measured slower on MI355X) and returns the previous setting; smirk_bn_fused_errors() synchronises the device and
  * returns the number of streams on which a grid barrier ever timed out (a grid that was not fully resident; results of that call are then invalid) — 0 always
  * in the tests and benchmarks. */
 int smirk_bn_set_fused(int on);

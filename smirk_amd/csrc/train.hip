@@ -48,7 +48,21 @@ inline unsigned blocks_for(size_t items, unsigned cap) {
 //   MODE 1 (BN backward)     f = dyh,          g = dyh * xhat      with dyh = dy * [relu ? (xhat*gamma+beta > 0) : 1], xhat = (z-mean)*invstd
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define RED_BLOCKS 512
-template <int MODE>
+// Device-coherent accesses for the few values workgroups of ONE launch hand to each other (bn_fused_kernel): relaxed agent-scope atomics are issued with the
+// cache-coherence bits set (write-through / read-through the per-XCD L2), so no fence is needed to make them visible across the eight XCDs.  The generic
+// alternative — __threadfence() = agent-scope release / acquire — writes back and invalidates the XCD's whole L2 on this part: a grid barrier built on it
+// cost ~150 us (measured: 331 us per one-launch BatchNorm against ~40 us for three dependent launches, gpurun_out/r02ah).
+template <bool DEV, typename T>
+__device__ __forceinline__ void st_x(T* p, T v) {
+    if (DEV) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool DEV, typename T>
+__device__ __forceinline__ T ld_x(const T* p) {
+    if (DEV) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <int MODE, bool DEV>
 __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
@@ -101,7 +115,7 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
         const int gg = o >> 4, k = o & 15;
         double a = 0.0;
         for (int r = 0; r < RPB; ++r) a += red[(r * G + gg) * 16 + k];
-        part[((size_t)blockIdx.x * G * 8 + gg * 8 + (k >> 1)) * 2 + (k & 1)] = a;
+        st_x<DEV>(&part[((size_t)blockIdx.x * G * 8 + gg * 8 + (k >> 1)) * 2 + (k & 1)], a);
     }
 }
 template <int MODE>
@@ -110,11 +124,12 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                      double* __restrict__ part /*[blocks][C][2]*/) {
     __shared__ double red[256 * 16];
-    colsum_partial<MODE>(z, dy, M, G, mean, invstd, gamma, beta, relu, part, red);
+    colsum_partial<MODE, false>(z, dy, M, G, mean, invstd, gamma, beta, relu, part, red);
 }
 
 // stage 2: the <= 512 per-block partials of a channel are summed by 16 threads (strided, fixed order) and combined in LDS in a fixed order;
 // one workgroup = 16 channels x 16 partial lanes.  (A single thread per channel walking 512 partials was 0.1 ms of pure load latency per launch.)
+template <bool DEV = false>
 __device__ __forceinline__ bool stage2_sum(const double* __restrict__ part, int nblocks, int C, int c, double& a, double& b, double (*red)[16][2]) {
     const int j = threadIdx.x >> 4, cl = threadIdx.x & 15;
     double sa = 0.0, sb = 0.0;
@@ -127,8 +142,8 @@ __device__ __forceinline__ bool stage2_sum(const double* __restrict__ part, int 
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + 16 * u;
                 const bool on = k < nblocks;
-                va[u] = on ? part[((size_t)k * C + c) * 2] : 0.0;
-                vb[u] = on ? part[((size_t)k * C + c) * 2 + 1] : 0.0;
+                va[u] = on ? ld_x<DEV>(&part[((size_t)k * C + c) * 2]) : 0.0;
+                vb[u] = on ? ld_x<DEV>(&part[((size_t)k * C + c) * 2 + 1]) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { sa += va[u]; sb += vb[u]; }
@@ -169,14 +184,15 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ 
 // The two BatchNorm element-wise kernels give every thread a FIXED 8-channel group and let it walk rows (256 / G rows in flight per block), so
 // the per-channel coefficients are loaded once into registers and no per-element index division is needed.
 // y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
-__device__ __forceinline__ void bn_apply_body(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
-                                              const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+template <bool DEV = false>
+__device__ __forceinline__ void bn_apply_body(const float* __restrict__ z, size_t M, int G, const float* mean,
+                                              const float* invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                               const float* __restrict__ residual, int relu, float* __restrict__ y) {
     const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
     if (rl >= RPB) return;
     float mu[8], is[8], ga[8], be[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
+    for (int q = 0; q < 8; ++q) { mu[q] = ld_x<DEV>(mean + g * 8 + q); is[q] = ld_x<DEV>(invstd + g * 8 + q); ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
     for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
         const size_t i = r * G + g;
         float v[8];
@@ -203,10 +219,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // dz = gamma * invstd * (dyh - sum_dyh / n - xhat * sum_dyh_xhat / n)
+template <bool DEV = false>
 __device__ __forceinline__ void bn_backward_apply_body(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
+                                                       const float* sum_dy, const float* sum_dy_xhat, int relu,
                                                        float* __restrict__ dz) {
     const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
     if (rl >= RPB) return;
@@ -214,7 +231,7 @@ __device__ __forceinline__ void bn_backward_apply_body(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = g * 8 + q;
-        mu[q] = mean[c]; is[q] = invstd[c]; ga[q] = gamma[c]; be[q] = beta[c]; s1[q] = sum_dy[c] * inv_n; s2[q] = sum_dy_xhat[c] * inv_n;
+        mu[q] = mean[c]; is[q] = invstd[c]; ga[q] = gamma[c]; be[q] = beta[c]; s1[q] = ld_x<DEV>(sum_dy + c) * inv_n; s2[q] = ld_x<DEV>(sum_dy_xhat + c) * inv_n;
     }
     for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
         const size_t i = r * G + g;
@@ -239,28 +256,29 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// One-launch BatchNorm for tensors whose three passes are shorter than the gaps between three dependent launches (everything below ~64 MB: the
-// encoders' ~135 layers and the generator's 14^2 / 28^2 levels — 279 BatchNorm calls per training step whose finalisation kernels alone were 3.7 ms
-// of pure launch gap).  A grid of <= 256 co-resident workgroups runs the SAME three stages — partial sums (colsum_partial), finalisation of 16 channels
-// per workgroup (stage2_sum's fixed order), element-wise pass — separated by two grid barriers: an arrival counter in device memory, release / acquire
-// fences, a bounded spin (a grid that for any reason is not fully resident raises a sticky error word instead of hanging the GPU; smirk_bn_fused_errors).
-// Counters are library-owned, one set per stream, and reset by the last workgroup to leave, so back-to-back launches on a stream need no memset.
-// With <= 256 workgroups of 36 KB LDS, four such grids (the three encoder streams + the generator) fit on the 256 CUs simultaneously.
+// One-launch BatchNorm (EXPERIMENT, opt-in: $SMIRK_BN_FUSED=1 / smirk_bn_set_fused): the 279 BatchNorm calls of a training step spend 3.7 ms in finalisation
+// kernels that are pure launch gap, so a grid of <= 256 co-resident workgroups runs the SAME three stages — partial sums (colsum_partial), finalisation of 16
+// channels per workgroup (stage2_sum's fixed order), element-wise pass — in one launch, separated by two grid barriers: an arrival counter in device memory,
+// device-coherent (cache-bypassing) accesses for the handful of values that cross workgroups instead of fences, a bounded spin (a grid that for any reason is
+// not fully resident raises a sticky error word instead of hanging the GPU; smirk_bn_fused_errors).  Counters are library-owned, one set per stream, and
+// reset by the last workgroup to leave.  Correct (tests/test_train_ops_gpu.py runs both forms) but SLOWER on MI355X, which is why it is not the default:
+//   * with __threadfence() (agent-scope release / acquire) a barrier writes back and invalidates the XCD's L2: 331 us per call (three launches: ~47 us);
+//   * with relaxed agent-scope atomics (sc1 loads / stores, no fences) 85 us per forward call, 71 us per backward call — a barrier across the eight XCDs
+//     still costs 15-20 us, and 256 workgroups stream the two data passes far below what the 2048-workgroup kernels reach.  train64: 52.6 vs 45.6 ms.
 // ---------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool grid_barrier(unsigned* cnt, unsigned target, int* flag_lds) {
-    __threadfence();                                        // release: this thread's global writes are visible device-wide
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's device-coherent stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
         for (int it = 0; it < (1 << 21); ++it) {
-            if (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(4);
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
         }
         *flag_lds = ok;
     }
     __syncthreads();
-    __threadfence();                                        // acquire: stale L1 lines are dropped before other workgroups' results are read
     return *flag_lds != 0;
 }
 
@@ -283,28 +301,28 @@ __global__ __launch_bounds__(256) void bn_fused_kernel(BnFusedArgs a) {
     __shared__ double red2[16][16][2];
     __shared__ int flag;
     const int C = a.G * 8, nb = gridDim.x;
-    colsum_partial<MODE>(a.z, a.dy, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.relu, a.part, red);
+    colsum_partial<MODE, true>(a.z, a.dy, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.relu, a.part, red);
     bool ok = grid_barrier(a.sync + 0, (unsigned)nb, &flag);
     for (int c0 = blockIdx.x * 16; c0 < C; c0 += nb * 16) {  // workgroup-uniform trip count: stage2_sum contains a barrier
         const int c = c0 + (threadIdx.x & 15);
         double sa, sb;
-        if (stage2_sum(a.part, nb, C, c, sa, sb, red2)) {
+        if (stage2_sum<true>(a.part, nb, C, c, sa, sb, red2)) {
             if (MODE == 0) {
                 const double n = (double)a.M, m = sa / n;
                 double v = sb / n - m * m;
                 if (v < 0.0) v = 0.0;
-                a.mean[c] = (float)m; a.var[c] = (float)v; a.invstd[c] = (float)(1.0 / sqrt(v + (double)a.eps));
+                st_x<true>(a.mean + c, (float)m); a.var[c] = (float)v; st_x<true>(a.invstd + c, (float)(1.0 / sqrt(v + (double)a.eps)));
                 if (a.running_mean) a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
                 if (a.running_var) a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
             } else {
-                a.dbeta[c] = (float)sa; a.dgamma[c] = (float)sb;
+                st_x<true>(a.dbeta + c, (float)sa); st_x<true>(a.dgamma + c, (float)sb);
             }
         }
         __syncthreads();                                    // red2 is reused by the next channel slab
     }
     ok = grid_barrier(a.sync + 1, (unsigned)nb, &flag) && ok;
-    if (MODE == 0) bn_apply_body(a.z, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.residual, a.relu, a.out);
-    else bn_backward_apply_body(a.z, a.dy, a.M, a.G, (float)(1.0 / (double)a.M), a.mean, a.invstd, a.gamma, a.beta, a.dbeta, a.dgamma, a.relu, a.out);
+    if (MODE == 0) bn_apply_body<true>(a.z, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.residual, a.relu, a.out);
+    else bn_backward_apply_body<true>(a.z, a.dy, a.M, a.G, (float)(1.0 / (double)a.M), a.mean, a.invstd, a.gamma, a.beta, a.dbeta, a.dgamma, a.relu, a.out);
     if (threadIdx.x == 0) {
         if (!ok) __hip_atomic_store(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // every workgroup takes its exit ticket AFTER it has seen barrier 2 complete, so nobody is spinning on the counters when the last one clears them
@@ -1060,7 +1078,10 @@ static bool g_bn_pool_failed = false;
 static std::unordered_map<hipStream_t, int> g_bn_slots;
 static int g_bn_fused_override = -1;
 static bool bn_fused_enabled() {
-    static const int env = [] { const char* e = getenv("SMIRK_BN_FUSED"); return e ? atoi(e) : 1; }();
+    // default OFF: measured slower than three launches on this 8-XCD part (85 vs 47 us per forward call, train64 step 52.6 vs 45.6 ms, gpurun_out/r02ai) —
+    // a grid barrier costs ~15-20 us even with cache-bypassing accesses, more than the gap between dependent launches, and 256 co-resident workgroups
+    // stream at a fraction of what 2048 do; kept selectable and tested
+    static const int env = [] { const char* e = getenv("SMIRK_BN_FUSED"); return e ? atoi(e) : 0; }();
     return (g_bn_fused_override >= 0 ? g_bn_fused_override : env) != 0;
 }
 // the stream's counter set, or nullptr when none can be had right now (first use while the stream is being captured into a graph: allocating would
