@@ -1254,7 +1254,8 @@ static int wgrad_nsplit(long long npix, int Cout, int N) {
     }
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const long long tiles = (long long)((Cout + TM - 1) / TM) * ((N + 127) / 128);
-    long long want = (TM == 128 ? 1024 : 1536) / tiles;                // 4 (TM = 128: 34 KB LDS each) / 6 workgroups per CU in ONE round (rounding up put 1152 on
+    static const int wg_env = [] { const char* e = getenv("SMIRK_WGRAD_SPLIT_WG"); return e ? atoi(e) : 0; }();   // A/B: workgroups the K splits should add up to
+    long long want = (wg_env > 0 ? wg_env : (TM == 128 ? 1024 : 1536)) / tiles;   // 4 (TM = 128: 34 KB LDS each) / 6 workgroups per CU in ONE round (rounding up put 1152 on
                                                                        // 1024 slots for the 512-channel layers: a second, 12 % full round)
     if (want > WG_MAX_SPLIT) want = WG_MAX_SPLIT;
     if (want > chunks) want = chunks;
