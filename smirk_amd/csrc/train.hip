@@ -1,16 +1,17 @@
 // Training-mode building blocks of the SmirkGenerator on MI355X (BASELINE config 5, first slice: the generator is 97 % of the step's FLOPs):
 //   * BatchNorm2d in TRAIN mode — batch statistics, normalise + affine (+ residual) (+ ReLU), running-stat update    (nn.BatchNorm2d inside
 //     smirk_generator.py:88-119 `_block` and :121-178 `ResnetBlock` after `self.train()`, base_trainer.py:108-111) — and its backward;
-//   * the backward companions of the forward kernels: weight gradient of 3x3 / 1x1 / transposed convolutions (exact fp32 MFMA), 2x2 max-pool
-//     backward, reflection-pad fold, space-to-depth of the ConvTranspose2d output gradient, final 1x1 conv + sigmoid backward.
+//   * the backward companions of the forward kernels: weight gradient of 3x3 / 1x1 / transposed convolutions (split-fp16 x3 on the fp16 matrix pipe
+//     with LDS transpose reads; exact fp32 MFMA selectable), 2x2 max-pool backward, reflection-pad fold, space-to-depth of the ConvTranspose2d output gradient, final 1x1 conv + sigmoid backward.
 // Data gradients of the convolutions need no kernel of their own: dX = conv(dZ, W rotated by 180 degrees with Cin <-> Cout swapped) runs on
 // the forward implicit-GEMM / ping-pong / halo-patch kernels (the host repacks the weights once per step).
 //
 // Activations and their gradients are split16 NHWC tensors (conv_common.h): every kernel here decodes 8-channel groups to fp32, computes in
 // fp32 (reductions in fp64, two-stage and in a fixed order => bit-reproducible) and re-splits.  All kernels are HBM-bound streaming kernels
-// except the weight gradient, which is MFMA-bound at the fp32 matrix rate (157 TFLOP/s): K = B*H*W pixels is the reduction, so both operands
-// are "k-major" in memory, which is exactly the operand layout of v_mfma_f32_32x32x2_f32 (one fp32 per lane: lanes 0-31 / 32-63 hold k, k+1) —
-// no transposition is needed, and the gradient is accumulated in exact fp32.
+// except the weight gradient, a GEMM whose reduction index is K = B*H*W pixels, so both operands are "k-major" in memory.  That is exactly the operand
+// layout of v_mfma_f32_32x32x2_f32 (one fp32 per lane: lanes 0-31 / 32-63 hold k, k+1) — the exact-fp32 kernels need no transposition but run at the fp32
+// matrix rate (157 TFLOP/s); the default kernels consume the split16 operands as stored on the 16x faster fp16 pipe and let ds_read_b64_tr_b16 produce
+// the k-contiguous fragments that pipe wants (wgrad_f16_kernel, wgrad3x3_halo_f16_kernel).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -833,7 +834,6 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x;
     const int cpr = a.W / 16;
-    const long long nchunk = (long long)a.B * a.H * cpr;
     f32x16 acc0[MAXB], acc1[MAXB];
 #pragma unroll
     for (int i = 0; i < MAXB; ++i)
