@@ -7,7 +7,7 @@ the batch and updates its running estimates, and the backward pass returns gradi
 Here the whole network is ONE torch.autograd.Function.  Forward: raw convolutions on the implicit-GEMM / ping-pong / halo-patch kernels, then
 `smirk_bn_train_forward_split16` (statistics, normalise, affine, residual, ReLU, running-stat update).  Backward walks the recorded tape:
 `smirk_bn_train_backward_split16`, data gradients on the SAME forward conv kernels with the weights rotated by 180 degrees and Cin <-> Cout
-swapped, weight gradients on `smirk_conv_wgrad_f32` (exact fp32 MFMA), max-pool / reflection-pad / ConvTranspose2d / sigmoid companions
+swapped, weight gradients on `smirk_conv_wgrad_f32` (split-fp16 x3 MFMA with LDS transpose reads; exact fp32 MFMA selectable), max-pool / reflection-pad / ConvTranspose2d / sigmoid companions
 (csrc/train.hip).  Arithmetic: split-fp16 x3 MFMA for the convolutions and their data gradients (fp32-class, like inference), fp32 / fp64 for
 statistics and weight gradients — tighter than the bf16 autocast BASELINE config 5 names.  The layer schedule lives in Python for now (a training
 step is ~25 ms of GPU time at B = 64; the host is not yet the limiter).
