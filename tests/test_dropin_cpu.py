@@ -74,3 +74,20 @@ def test_shim_exposes_the_reference_module_paths(monkeypatch):
         for n in names:
             assert hasattr(m, n), (mod, n)
         assert m.__file__.startswith(os.path.join(REPO, "integration", "shim"))
+
+
+def test_graph_cycle_modules_refuses_eval_mode():
+    """smirk_amd.cycle.graph_cycle_modules captures the TRAIN-mode path only (batch-statistics BatchNorm + backward); asking for it in eval mode is an error, raised
+    before anything touches a device"""
+    import torch
+    from smirk_amd.cycle import CYCLE_GRAD_KEYS, _CycleEncoder, graph_cycle_modules
+
+    class Tiny(torch.nn.Module):
+        def forward(self, x):
+            return {k: x.mean() * (i + 1) for i, k in enumerate(CYCLE_GRAD_KEYS + ("pose_params", "cam"))}
+
+    g, e = torch.nn.Conv2d(6, 3, 1).eval(), Tiny().eval()
+    with pytest.raises(ValueError):
+        graph_cycle_modules(g, e, torch.zeros(1, 6, 16, 16), torch.zeros(1, 3, 16, 16))
+    out = _CycleEncoder(Tiny())(torch.ones(1, 3, 4, 4, requires_grad=True))          # the wrapper detaches what the cycle loss does not differentiate
+    assert all(out[k].requires_grad for k in CYCLE_GRAD_KEYS) and not out["pose_params"].requires_grad and not out["cam"].requires_grad
