@@ -21,8 +21,10 @@ ARCH = "gfx950"
 # fp16 MFMAs + ds_read_b128 (the generator's implicit-GEMM kernels, launched from a second stream) is resident on the same CU — FLAME
 # vertices and rendered pixels were corrupted in 10/10 concurrent trials with the packed instructions and in 0/10 without them; waits,
 # barriers, LDS contents and out-of-bounds writes were all ruled out first.  The two-stream pipeline needs that co-residency, so the packed
-# forms are not generated at all (cost: < 1 % on the conv epilogues, nothing measurable end to end).
-COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+# forms are not generated at all (cost: < 1 % on the conv epilogues, nothing measurable end to end).  -fno-vectorize: the LOOP vectoriser
+# produces the same packed forms (round 2 shipped two v_pk_add_f32 in maxfilter1d_kernel that way); tests/test_isa_cpu.py disassembles
+# the built library and fails on any v_pk_{add,mul,fma}_f32.
+COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-fno-vectorize"]
 PER_FILE = {"render.hip": ["-ffp-contract=off"], "video.hip": ["-ffp-contract=off"]}
 
 

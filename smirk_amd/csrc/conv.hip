@@ -614,6 +614,10 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
 bool smirk_conv_pp_eligible(const ConvArgs& a);
 int smirk_conv_pp_launch(const ConvArgs& a, hipStream_t st);
 
+// conv_halo.hip: the ping-pong schedule with the A operand staged once per channel chunk (one pixel halo serves all nine taps)
+bool smirk_conv_halo_eligible(const ConvArgs& a);
+int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st);
+
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
 bool smirk_conv3x3_patch_eligible(const SmirkConvDesc* d, bool has_residual);
 int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
@@ -680,6 +684,7 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
     if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
+    if (split && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st);
     if (split && smirk_conv_pp_eligible(a)) return smirk_conv_pp_launch(a, st);
     if (split) {
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);

@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void points_to_pixels_kernel(const float* __re
 }
 
 // one pass of a separable (2r+1) max filter with -inf padding; dir 0 = along x, 1 = along y.  in/out [B][H][W]
+// Generic fallback (any radius / width); the shipped sizes take maxpool_sq_lds_kernel below.  vectorize(disable): the loop vectoriser turned
+// the complement + max chain into v_pk_add_f32, an instruction class that must not appear in this library (build.py).
 __global__ __launch_bounds__(256) void maxfilter1d_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                                           int r, int dir, int complement_in, int complement_out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,12 +105,82 @@ __global__ __launch_bounds__(256) void maxfilter1d_kernel(const float* __restric
     float m = -INFINITY;
     if (dir == 0) {
         const int lo = max(x - r, 0), hi = min(x + r, W - 1);
+#pragma clang loop vectorize(disable) interleave(disable)
         for (int k = lo; k <= hi; ++k) { float v = in[base + (size_t)y * W + k]; if (complement_in) v = 1.0f - v; m = fmaxf(m, v); }
     } else {
         const int lo = max(y - r, 0), hi = min(y + r, H - 1);
+#pragma clang loop vectorize(disable) interleave(disable)
         for (int k = lo; k <= hi; ++k) { float v = in[base + (size_t)k * W + x]; if (complement_in) v = 1.0f - v; m = fmaxf(m, v); }
     }
     out[i] = complement_out ? 1.0f - m : m;
+}
+
+// (2R+1)^2 max pool, both passes in ONE launch: a workgroup owns MP_ROWS output rows of one image over the full width.  It stages the
+// rows [y0-R, y0+MP_ROWS+R) once in LDS (complemented on the way in if asked; -inf outside the image and in an R-wide margin left and
+// right), runs the x pass LDS -> LDS with every thread producing 4 neighbouring outputs from 4+2R staged values (6 LDS reads per output
+// instead of 21 global ones), then the y pass the same way down a column (lanes are neighbouring x: conflict-free) and writes the result.
+// max is exact and order-free, so the output equals the two-pass form bit for bit (tests/test_masking_gpu.py).
+#define MP_ROWS 32
+template <int R>
+__global__ __launch_bounds__(512) void maxpool_sq_lds_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                            int complement_in, int complement_out) {
+    extern __shared__ float mp_lds[];
+    const int SW = W + 2 * R;                           // staged row stride (margins included)
+    const int NR = MP_ROWS + 2 * R;                     // staged rows
+    float* A = mp_lds;                                  // [NR][SW]  input rows
+    float* Hx = mp_lds + NR * SW;                       // [NR][W]   after the x pass
+    const int tiles = (H + MP_ROWS - 1) / MP_ROWS;
+    const int b = blockIdx.x / tiles, y0 = (blockIdx.x % tiles) * MP_ROWS;
+    const float* src = in + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < NR * SW; i += 512) {
+        const int rr = i / SW, cx = i - rr * SW - R, y = y0 - R + rr;
+        float v = -INFINITY;
+        if (y >= 0 && y < H && cx >= 0 && cx < W) { v = src[(size_t)y * W + cx]; if (complement_in) v = 1.0f - v; }
+        A[i] = v;
+    }
+    __syncthreads();
+    const int W4 = (W + 3) / 4;
+    for (int i = threadIdx.x; i < NR * W4; i += 512) {
+        const int rr = i / W4, x = (i - rr * W4) * 4;
+        const float* a = A + rr * SW + x;              // a[k] = column x - R + k
+        float v[4 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) v[k] = (x + k < SW) ? a[k] : -INFINITY;
+        float c = v[3];
+#pragma unroll
+        for (int k = 4; k <= 2 * R; ++k) c = fmaxf(c, v[k]);
+        const float o0 = fmaxf(fmaxf(c, v[2]), fmaxf(v[1], v[0]));
+        const float o1 = fmaxf(fmaxf(c, v[2]), fmaxf(v[1], v[2 * R + 1]));
+        const float o2 = fmaxf(fmaxf(c, v[2]), fmaxf(v[2 * R + 2], v[2 * R + 1]));
+        const float o3 = fmaxf(fmaxf(c, v[2 * R + 3]), fmaxf(v[2 * R + 2], v[2 * R + 1]));
+        float* h = Hx + rr * W + x;
+        h[0] = o0;
+        if (x + 1 < W) h[1] = o1;
+        if (x + 2 < W) h[2] = o2;
+        if (x + 3 < W) h[3] = o3;
+    }
+    __syncthreads();
+    float* dst = out + (size_t)b * H * W;
+    for (int i = threadIdx.x; i < (MP_ROWS / 4) * W; i += 512) {
+        const int q = i / W, x = i - q * W;
+        const float* h = Hx + (q * 4) * W + x;        // h[k * W] = staged row q*4 + k = image row y0 + q*4 - R + k
+        float v[4 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) v[k] = h[k * W];
+        float c = v[3];
+#pragma unroll
+        for (int k = 4; k <= 2 * R; ++k) c = fmaxf(c, v[k]);
+        float o[4];
+        o[0] = fmaxf(fmaxf(c, v[2]), fmaxf(v[1], v[0]));
+        o[1] = fmaxf(fmaxf(c, v[2]), fmaxf(v[1], v[2 * R + 1]));
+        o[2] = fmaxf(fmaxf(c, v[2]), fmaxf(v[2 * R + 2], v[2 * R + 1]));
+        o[3] = fmaxf(fmaxf(c, v[2 * R + 3]), fmaxf(v[2 * R + 2], v[2 * R + 1]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = y0 + q * 4 + k;
+            if (y < H) dst[(size_t)y * W + x] = complement_out ? 1.0f - o[k] : o[k];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bernoulli_field_kernel(float* __restrict__ out, size_t n, float p, uint64_t seed, uint64_t offset) {
@@ -238,9 +310,29 @@ extern "C" int smirk_points_to_pixels(const float* points, int B, int L, int ima
     return smirk_launch_status();
 }
 
+template <int R>
+static void launch_maxpool_lds(const float* in, float* out, int B, int H, int W, int complement, hipStream_t st) {
+    const size_t lds = ((size_t)(MP_ROWS + 2 * R) * (W + 2 * R) + (size_t)(MP_ROWS + 2 * R) * W) * sizeof(float);
+    static bool attr_done[64] = {};                    // per device: the attribute is per-device state (one process may drive several GPUs)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)maxpool_sq_lds_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[dev] = true;
+    }
+    const int tiles = (H + MP_ROWS - 1) / MP_ROWS;
+    smirk_prof_next(nullptr, 0.0, 2.0 * B * H * W * sizeof(float));
+    SMIRK_LAUNCH(maxpool_sq_lds_kernel<R>, dim3((unsigned)(B * tiles)), dim3(512), lds, st, in, out, H, W, complement & 1, (complement >> 1) & 1);
+}
+
 extern "C" int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int W, int radius, int complement, void* stream) {
-    if (!in || !tmp || !out || B <= 0 || radius < 0) return SMIRK_ERR_BAD_ARG;
+    if (!in || !tmp || !out || B <= 0 || H <= 0 || W <= 0 || radius < 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)B * H * W;
+    // the fused LDS form covers the radii the reference uses (masking.py:78 -> 10, :96 -> 5) at widths whose staged rows fit 160 KB of LDS
+    const size_t staged = (size_t)(MP_ROWS + 2 * radius) * (2 * (size_t)W + 2 * radius) * sizeof(float);
+    const bool lds_ok = staged <= 160 * 1024 && (size_t)B * ((H + MP_ROWS - 1) / MP_ROWS) < 0x7fffffffull;
+    if (lds_ok && radius == 10) { launch_maxpool_lds<10>(in, out, B, H, W, complement, (hipStream_t)stream); return smirk_launch_status(); }
+    if (lds_ok && radius == 5) { launch_maxpool_lds<5>(in, out, B, H, W, complement, (hipStream_t)stream); return smirk_launch_status(); }
     SMIRK_LAUNCH(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in, tmp, B, H, W, radius, 0, complement & 1, 0);
     SMIRK_LAUNCH(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, out, B, H, W, radius, 1, 0,
                        (complement >> 1) & 1);

@@ -112,12 +112,14 @@ def graph_cycle_modules(generator, encoder, generator_input, encoder_input, grad
     return torch.cuda.make_graphed_callables((gen, enc), ((gi,), (ei,)), num_warmup_iters=warmup, allow_unused_input=True)
 
 
-def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True):
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True, force_collective=False):
     """Data-parallel gradient exchange (C2): flatten the gradients into few large buckets, one all-reduce each (RCCL over xGMI on GPUs, gloo in the
     CPU tests), scatter back.  Parameters without a gradient on this rank are skipped on EVERY rank only if they are skipped everywhere — the trainer
     freezes the same modules on all ranks, and the bucket layout is derived from `requires_grad`, not from `.grad is None`, so ranks cannot disagree."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return 0
+    if dist.get_world_size(group) == 1 and not force_collective:       # force_collective: a one-GPU job still drives RCCL (tests/test_rccl_gpu.py)
         return 0
     world = dist.get_world_size(group)
     todo = [p for p in params if p.requires_grad]

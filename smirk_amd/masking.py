@@ -16,9 +16,26 @@ import torch
 from . import _lib as L
 from .renderer import normal_csr
 
-def _rng(n_draws):
-    """(seed, offset) of the Philox counters for one call: the key is torch's global seed and the counter base is drawn from torch's
-    default (CPU) generator, so `torch.manual_seed(s)` makes a whole sequence of calls reproducible while successive calls differ."""
+class PhiloxStream:
+    """Explicit state of this module's random draws: key `seed`, running counter `offset`.  Every kernel that draws takes
+    (seed, offset) and consumes `n_draws` counters; passing the same PhiloxStream(seed, offset) to two runs makes them draw the same
+    numbers whatever else touched torch's generators in between (tests pin the bench schedule this way)."""
+
+    def __init__(self, seed, offset=0):
+        self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset)
+
+    def __call__(self, n_draws):
+        off = self.offset
+        self.offset += int(n_draws)
+        return self.seed, off
+
+
+def _rng(n_draws, stream=None):
+    """(seed, offset) of the Philox counters for one call.  Default: the key is torch's global seed and the counter base is drawn from
+    torch's default (CPU) generator, so `torch.manual_seed(s)` makes a whole sequence of calls reproducible while successive calls differ;
+    with an explicit PhiloxStream the draw does not touch torch's generators at all."""
+    if stream is not None:
+        return stream(n_draws)
     seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
     off = int(torch.randint(0, 2 ** 62, (1,)).item())
     return seed, off
@@ -59,7 +76,7 @@ def _maxpool_sq(x, radius, complement):
 
 
 def masking(img, mask, extra_points, wr=15, rendered_mask=None, extra_noise=True, random_mask=0.01, _noise_mult=None, _random_field=None,
-            _pmask=None):
+            _pmask=None, _rng_stream=None):
     """masking.py:71-102.  img [B,C,H,W], mask / rendered_mask [B,1,H,W], extra_points [B,C,H,W] -> masked_img [B,C,H,W].
     `_noise_mult` ([B,C,H,W]) and `_random_field` ([B,1,H,W] of 0/1 patch centres) override the random draws (tests);
     `_pmask` ([B,1,H,W]) with extra_points=None fuses the caller's `extra_points = img * pmask` (demo.py:163)."""
@@ -83,14 +100,14 @@ def masking(img, mask, extra_points, wr=15, rendered_mask=None, extra_noise=True
     if random_mask > 0 or _random_field is not None:
         if _random_field is None:
             field = torch.empty(B, 1, H, W, device=img.device)
-            seed, off = _rng((B * H * W + 3) // 4)
+            seed, off = _rng((B * H * W + 3) // 4, _rng_stream)
             L.check(lib.smirk_bernoulli_field(L.ptr(field), field.numel(), float(random_mask), seed, off, st))
         else:
             field = L.as_f32c(_random_field)
         keep = _maxpool_sq(field, 5, complement=2)                           # 1 - maxpool(centres, 11): zero inside the 11x11 patches
     out = torch.empty_like(img)
     noise = None if _noise_mult is None else L.as_f32c(_noise_mult)
-    seed, off = _rng(img.numel()) if (extra_noise and noise is None) else (0, 0)
+    seed, off = _rng(img.numel(), _rng_stream) if (extra_noise and noise is None) else (0, 0)
     pm = None if _pmask is None else L.as_f32c(_pmask)
     L.check(lib.smirk_masking_compose(L.ptr(img), L.ptr(mask_d), L.ptr(rm, allow_none=True), L.ptr(extra_points, allow_none=True),
                                       L.ptr(pm, allow_none=True), L.ptr(keep, allow_none=True), L.ptr(noise, allow_none=True), B, C, H, W,
@@ -144,7 +161,8 @@ def _full_mesh(flame_faces):
     return _mesh_cache[key]
 
 
-def mesh_based_mask_uniform_faces(flame_trans_verts, flame_faces, face_probabilities, mask_ratio=0.1, coords=None, IMAGE_SIZE=224):
+def mesh_based_mask_uniform_faces(flame_trans_verts, flame_faces, face_probabilities, mask_ratio=0.1, coords=None, IMAGE_SIZE=224,
+                                  _rng_stream=None):
     """masking.py:132-181: sample `int(mask_ratio * IMAGE_SIZE**2)` points on the visible, region-weighted FLAME surface and return
     their integer pixel coordinates [B,N,3] (x, y, z) plus {'sampled_faces_indices' [B,N] int64, 'barycentric_coords' [B,N,3]}."""
     tv = L.as_f32c(flame_trans_verts)
@@ -162,7 +180,7 @@ def mesh_based_mask_uniform_faces(flame_trans_verts, flame_faces, face_probabili
         L.check(lib.smirk_mask_face_weights(L.ptr(tv), L.ptr(normals), L.ptr(bufs['faces'], torch.int32), L.ptr(prob), B, V, F, L.ptr(wts), st))
         idx = torch.empty(B, n, dtype=torch.int32, device=dev)
         bary = torch.empty(B, n, 3, device=dev)
-        seed, off = _rng(B * n)
+        seed, off = _rng(B * n, _rng_stream)
         L.check(lib.smirk_sample_faces(L.ptr(wts), B, F, n, seed, off, L.ptr(idx, torch.int32), L.ptr(bary), st))
     else:
         idx = coords['sampled_faces_indices'].to(torch.int32).contiguous()
@@ -195,17 +213,18 @@ def points_mask(npoints, H, W, rbound=None):
 
 
 def demo_masked_image(img, hull_mask, rendered_img, transformed_vertices, flame_faces, face_probabilities,
-                      mask_ratio=0.01, mask_ratio_mul=5, mask_dilation_radius=10):
+                      mask_ratio=0.01, mask_ratio_mul=5, mask_dilation_radius=10, rng=None):
     """The block demo.py:138-165 runs between Renderer and SmirkGenerator, on the GPU: rendered mask, mesh-based point sampling with a
-    random per-image budget, point mask, masking().  Returns masked_img [B,3,H,W]."""
+    random per-image budget, point mask, masking().  Returns masked_img [B,3,H,W].  `rng`: an optional PhiloxStream that pins every
+    draw of the block (sampled faces + barycentrics, per-image budgets, patch centres, point noise) independently of torch's generators."""
     B, _, H, W = img.shape
     rmask = rendered_mask_of(rendered_img)
     npoints, _ = mesh_based_mask_uniform_faces(transformed_vertices, flame_faces, face_probabilities, mask_ratio=mask_ratio * mask_ratio_mul,
-                                               IMAGE_SIZE=H)
+                                               IMAGE_SIZE=H, _rng_stream=rng)
     # demo.py:154-156 draws rsing / rscale per image on the host and copies the budgets over; here they are drawn on the device (Philox keyed
     # like the other draws of this module) so the step has no host round trip and can be captured in a hipGraph
     rbound = torch.empty(B, dtype=torch.int64, device=img.device)
-    seed, off = _rng(B)
+    seed, off = _rng(B, rng)
     L.check(L.lib().smirk_random_point_budget(L.ptr(rbound, torch.int64), B, int(npoints.size(1)), float(mask_ratio_mul), seed, off, L.stream_ptr()))
     pmask = points_mask(npoints, H, W, rbound)
-    return masking(img, hull_mask, None, mask_dilation_radius, rendered_mask=rmask, _pmask=pmask)
+    return masking(img, hull_mask, None, mask_dilation_radius, rendered_mask=rmask, _pmask=pmask, _rng_stream=rng)

@@ -26,15 +26,16 @@ class SmirkPipeline:
         self.encoder, self.flame, self.renderer, self.generator = encoder, flame, renderer, generator
         self.face_probabilities = face_probabilities      # enables hull_mask= (masking utilities, demo.py:138-165)
 
-    def masked_from_hull(self, img, hull_mask, rn):
+    def masked_from_hull(self, img, hull_mask, rn, rng=None):
         from . import masking as M
         if self.face_probabilities is None:
             raise ValueError("SmirkPipeline(face_probabilities=masking.load_probabilities_per_FLAME_triangle()) is required for hull_mask=")
         return M.demo_masked_image(img, hull_mask, rn['rendered_img'], rn['transformed_vertices'], self.flame.faces_tensor,
-                                   self.face_probabilities)
+                                   self.face_probabilities, rng=rng)
 
     @torch.no_grad()
-    def __call__(self, img, masked_img=None, with_landmarks=True, hull_mask=None):
+    def __call__(self, img, masked_img=None, with_landmarks=True, hull_mask=None, mask_rng=None):
+        """`mask_rng`: optional masking.PhiloxStream pinning the random draws of the hull_mask= path (default: keyed by torch's seed)."""
         enc = self.encoder(img)
         fl = self.flame.forward(enc)
         lm = dict(landmarks_fan=fl['landmarks_fan'], landmarks_mp=fl['landmarks_mp']) if with_landmarks else {}
@@ -43,7 +44,7 @@ class SmirkPipeline:
         out.update(vertices=fl['vertices'], landmarks_fan_3d=fl['landmarks_fan_3d'], **rn)
         if self.generator is not None:
             if masked_img is None and hull_mask is not None:
-                masked_img = self.masked_from_hull(img, hull_mask, rn)
+                masked_img = self.masked_from_hull(img, hull_mask, rn, mask_rng)
                 out['masked_img'] = masked_img
             if masked_img is None:
                 raise ValueError("the generator needs the masked image (or hull_mask=) next to the rendering")
@@ -94,8 +95,8 @@ class OverlappedPipeline:
                 gs.wait_event(ev)
                 g = self.pipe.generator
                 if isinstance(masked, tuple):                   # ("hull", img, hull_mask): masking utilities run with the generator stage
-                    _, im, hull = masked
-                    masked = self.pipe.masked_from_hull(im, hull, out)
+                    _, im, hull, rng = masked
+                    masked = self.pipe.masked_from_hull(im, hull, out, rng)
                     out['masked_img'] = masked
                     for t in (out['transformed_vertices'], im, hull):
                         t.record_stream(gs)
@@ -119,7 +120,7 @@ class OverlappedPipeline:
         return out
 
     @torch.no_grad()
-    def submit(self, img, masked_img=None, with_landmarks=True, hull_mask=None):
+    def submit(self, img, masked_img=None, with_landmarks=True, hull_mask=None, mask_rng=None):
         self._streams(img.device)
         caller = torch.cuda.current_stream()
         ready = torch.cuda.Event()
@@ -138,7 +139,7 @@ class OverlappedPipeline:
             ev = torch.cuda.Event()
             ev.record(self.front_stream)
             img.record_stream(self.front_stream)
-        self._waiting.append((out, masked_img if hull_mask is None else ("hull", img, hull_mask), ev))
+        self._waiting.append((out, masked_img if hull_mask is None else ("hull", img, hull_mask, mask_rng), ev))
         return prev
 
     def flush(self):
@@ -152,18 +153,25 @@ class OutputGatherer:
 
     `start()` enqueues the collectives asynchronously into preallocated [world*n, ...] buffers and returns; `wait()` blocks
     until the previous start() has landed.  Typical loop:  out = pipe(x); g.wait(); g.start(out)  — the gather of batch i
-    overlaps the compute of batch i+1."""
+    overlaps the compute of batch i+1.
+
+    Stream contract: the collective runs on the process group's own stream.  c10d makes that stream wait for the CURRENT stream at the
+    time of start() (so outputs produced on the current stream are complete before they are sent) and `wait()` makes the current stream
+    wait for the collective; inputs and outputs are `record_stream`-ed on the communication stream by c10d, and `_hold` keeps the inputs
+    referenced until wait().  With `force_collective=True` a world of ONE still issues the real collective (a single MI355X then exercises
+    RCCL's all_gather_into_tensor end to end: tests/test_rccl_gpu.py); the default short-circuits it."""
 
     KEYS = ('vertices', 'rendered_img', 'reconstructed_img')
 
-    def __init__(self, keys=KEYS, group=None):
+    def __init__(self, keys=KEYS, group=None, force_collective=False):
         self.keys, self.group = tuple(keys), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force_collective) and dist.is_initialized()
         self.bufs, self.pending, self._hold, self._pool = {}, [], None, {}
 
     def start(self, outputs):
         self._hold = {k: outputs[k].contiguous() for k in self.keys if k in outputs}
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self.bufs = dict(self._hold)
             return
         for k, t in self._hold.items():

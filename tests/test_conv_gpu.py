@@ -90,6 +90,7 @@ def test_conv_pingpong_kernel_matches_fp64_and_the_128x128_kernel_bitwise(cfg):
     within tolerance of torch fp64, and BIT-IDENTICAL to the kernel it replaces (SMIRK_IGEMM_PP=0)."""
     import os
     from smirk_amd.smirk_generator import split16_to_float
+    os.environ["SMIRK_IGEMM_HALO"] = "0"             # conv_halo.hip takes these shapes first by default
     os.environ["SMIRK_IGEMM_PP"] = "all"             # also the 28x28 / 56x56 shapes the dispatcher leaves on the 128x128 kernel by default
     try:
         ref, a = _run(**cfg, only_split=True)
@@ -99,7 +100,36 @@ def test_conv_pingpong_kernel_matches_fp64_and_the_128x128_kernel_bitwise(cfg):
     try:
         _, b = _run(**cfg, only_split=True)
     finally:
-        del os.environ["SMIRK_IGEMM_PP"]
+        del os.environ["SMIRK_IGEMM_PP"], os.environ["SMIRK_IGEMM_HALO"]
+    assert (split16_to_float(a).cpu().double() - ref).abs().max().item() < TOL
+    assert torch.equal(a, b)
+
+
+# shapes served by the halo-staged ping-pong kernel (conv_halo.hip): every PP case plus images narrower / wider than the tile's row structure,
+# tiles that straddle several images (14x14: 1.3 images per 256-row tile), ragged last tiles, zero and reflect padding, two sources with different widths
+# (an even number of 32-channel chunks everywhere: that is when the 128x128 kernel walks K channel-major too, the order the bitwise comparison needs)
+HALO_CASES = PP_CASES + [dict(B=11, H=14, C0=512, C1=0, Cout=512), dict(B=6, H=14, C0=128, C1=64, Cout=128, reflect=True),
+                         dict(B=2, H=56, C0=128, C1=0, Cout=128, reflect=True), dict(B=3, H=31, C0=64, C1=0, Cout=128),
+                         dict(B=2, H=32, C0=64, C1=0, Cout=128, reflect=True), dict(B=1, H=63, C0=64, C1=128, Cout=256),
+                         dict(B=300, H=2, C0=64, C1=0, Cout=128, reflect=True), dict(B=40, H=6, C0=128, C1=0, Cout=128)]
+
+
+@pytest.mark.parametrize("cfg", HALO_CASES)
+def test_conv_halo_kernel_matches_fp64_and_the_128x128_kernel_bitwise(cfg):
+    """conv_halo_kernel stages one pixel halo per channel chunk and reads all nine taps from it; K order and per-accumulator MFMA sequence are those of
+    conv_igemm_kernel's channel-major walk: within tolerance of torch fp64 and BIT-IDENTICAL to the 128x128 kernel (SMIRK_IGEMM_HALO=0, SMIRK_IGEMM_PP=0)."""
+    import os
+    from smirk_amd.smirk_generator import split16_to_float
+    os.environ["SMIRK_IGEMM_HALO"] = "all"
+    try:
+        ref, a = _run(**cfg, only_split=True)
+    finally:
+        del os.environ["SMIRK_IGEMM_HALO"]
+    os.environ["SMIRK_IGEMM_HALO"] = "0"; os.environ["SMIRK_IGEMM_PP"] = "0"
+    try:
+        _, b = _run(**cfg, only_split=True)
+    finally:
+        del os.environ["SMIRK_IGEMM_HALO"], os.environ["SMIRK_IGEMM_PP"]
     assert (split16_to_float(a).cpu().double() - ref).abs().max().item() < TOL
     assert torch.equal(a, b)
 

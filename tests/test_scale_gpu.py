@@ -197,3 +197,76 @@ def test_pipeline_hull_mask_path_finite_B128(mods, sandbox):
     assert ((m[nz] - img[nz]).abs() <= 0.3 * img[nz] + 1e-6).all()
     assert (m[nz] == img[nz]).float().mean().item() > 0.5
     assert 0.05 < nz.float().mean().item() < 0.95
+
+
+@pytest.mark.parametrize("B", [128, 1024])
+def test_overlapped_hull_mask_schedule_is_bitwise_the_serial_pipeline(mods, sandbox, B):
+    """The schedule bench.py times by default: OverlappedPipeline.submit(img, hull_mask=...) — the masking utilities (demo.py:138-165) run on
+    the generator stream while the next batch's encoder / FLAME / renderer kernels are co-resident on the front stream.  With the Philox
+    stream pinned (masking.PhiloxStream), 8 repetitions with 1 and 2 generator streams must equal the serial SmirkPipeline(..., hull_mask=...)
+    bit for bit on EVERY key including masked_img.  B = 128 is a rank's shard on 8 GPUs, B = 1024 the one-GPU bench pass."""
+    from smirk_amd import masking as MK
+    from smirk_amd.pipeline import OverlappedPipeline, SmirkPipeline
+    cwd = os.getcwd(); os.chdir(sandbox)
+    try:
+        fp = MK.load_probabilities_per_FLAME_triangle().cuda()
+    finally:
+        os.chdir(cwd)
+    pipe = SmirkPipeline(mods["enc"], mods["flame"], mods["rend"], mods["gen"], face_probabilities=fp)
+    batches = []
+    for s in (9101, 9102):
+        n = min(B, 128)                                     # 128 distinct synthetic frames, tiled to B (the CPU synthesis is the slow part)
+        img = A.synth_images(n, seed=s)
+        hull = (A.synth_generator_input(n, seed=s)[:, 3:4] != 0).float()
+        rep = B // n
+        batches.append((img.repeat(rep, 1, 1, 1).contiguous().cuda(), hull.repeat(rep, 1, 1, 1).contiguous().cuda()))
+    SEED, OFF = 0x5EED5EED, (1 << 40)
+
+    def rng(i):
+        return MK.PhiloxStream(SEED + i, OFF)
+
+    first = [pipe(im, hull_mask=hu, mask_rng=rng(i)) for i, (im, hu) in enumerate(batches)]
+    torch.cuda.synchronize()
+    keys = [k for k, v in first[0].items() if torch.is_tensor(v)]
+    assert "masked_img" in keys and "reconstructed_img" in keys and "vertices" in keys
+    for o in first:
+        for k in keys:
+            assert torch.isfinite(o[k].float()).all(), k
+        assert (o["masked_img"] != 0).float().mean().item() > 0.05
+    # the draws depend on the stream state only: a second serial run reproduces the first
+    again = pipe(batches[0][0], hull_mask=batches[0][1], mask_rng=rng(0))
+    for k in keys:
+        assert torch.equal(again[k], first[0][k]), ("serial repeat", k)
+    del again
+    for trial in range(8):
+        run = OverlappedPipeline(pipe, generator_streams=1 + trial % 2)
+        got = [run.submit(im, hull_mask=hu, mask_rng=rng(i)) for i, (im, hu) in enumerate(batches)]
+        while True:
+            o = run.flush()
+            if o is None:
+                break
+            got.append(o)
+        got = [o for o in got if o is not None]
+        assert len(got) == 2
+        torch.cuda.synchronize()
+        for a, b in zip(first, got):
+            for k in keys:
+                assert torch.equal(a[k], b[k]), (trial, k)
+        del got, run
+
+
+@pytest.mark.parametrize("radius,comp", [(10, 3), (5, 2), (10, 0), (5, 1), (3, 3), (15, 3)])
+@pytest.mark.parametrize("shape", [(3, 224, 224), (2, 37, 53), (1, 64, 300)])
+def test_maxpool_sq_fused_lds_kernel_equals_max_pool2d(radius, comp, shape):
+    """smirk_maxpool_sq (masking.py:78,96): the one-launch LDS kernel (radius 5 / 10) and the generic two-pass fallback against
+    F.max_pool2d with -inf padding, ragged heights / widths included; exact (max and 1 - x are exact)."""
+    from smirk_amd import masking as MK
+    B, H, W = shape
+    g = torch.Generator().manual_seed(radius * 100 + comp + H)
+    x = (torch.rand(B, 1, H, W, generator=g) < 0.02).float() * torch.rand(B, 1, H, W, generator=g)
+    x = x.cuda()
+    got = MK._maxpool_sq(x, radius, comp)
+    src = 1 - x if comp & 1 else x
+    want = torch.nn.functional.max_pool2d(src, 2 * radius + 1, 1, radius)
+    want = 1 - want if comp & 2 else want
+    assert torch.equal(got, want)
