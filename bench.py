@@ -575,9 +575,9 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
         return None
     dom = max(per, key=lambda k: per[k][2])
     fl, by, tm, n = per[dom]
-    split = ",true," in dom or dom.endswith("true>") or dom.startswith("conv_pp_kernel") or "_f16_kernel" in dom      # split-fp16 (f16x3) kernels
+    split = ",true," in dom or dom.endswith("true>") or dom.startswith(("conv_pp_kernel", "conv_halo_kernel")) or "_f16_kernel" in dom      # split-fp16 (f16x3) kernels
     # wgrad_kernel / wgrad3x3_halo_kernel: exact-fp32 MFMA; wgrad_f16_kernel / wgrad3x3_halo_f16_kernel: split-fp16 x3 (LDS transpose reads)
-    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "flame_blend_skin", "flame_bwd", "wgrad_kernel", "wgrad_f16_kernel", "wgrad3x3_halo"))
+    gemm = dom.startswith(("conv_igemm_kernel", "conv_pp_kernel", "conv_halo_kernel", "flame_blend_skin", "flame_bwd", "wgrad_kernel", "wgrad_f16_kernel", "wgrad3x3_halo"))
     traffic = None
     if traffic_table:
         key = dom.split("[")[0]                                   # the profiler appends a "[tile,waves,stages]" tag to some names

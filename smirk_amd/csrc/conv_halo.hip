@@ -29,9 +29,24 @@
 #define HS_NSTAGE 3
 #define HS_BRING_BYTES (HS_NSTAGE * HS_BN * 128) /* 49,152 B */
 #define HS_EPI_LD (2 * 32 + 4)
-#define HS_DEFAULT_MAX_PIXELS 256                /* geometries the dispatcher sends here by default (H*W); "all" lifts it — set from measurements */
+#define HS_DEFAULT_EB 0
 
 typedef __attribute__((address_space(3))) void* hs_lptr_t;
+
+// Phase timeline (tools/halo_timeline.py), compiled only into -DSMIRK_DEBUG_HOOKS variant builds (tools/build_variant.sh): waves 0 and 4 of a few
+// workgroups stamp s_memtime at the four phase boundaries of every chunk into spare LDS and dump it at the end of the kernel.
+#ifdef SMIRK_DEBUG_HOOKS
+__device__ long long* g_hs_dbg = nullptr;                            // [8 workgroups][2 waves][HS_DBG_N] stamps
+#define HS_DBG_N 1024
+#define HS_DBG_LDS (2 * HS_DBG_N * 8)
+#define HS_STAMP()                                                                                             \
+    do {                                                                                                       \
+        if (dbg_on && dbg_i < HS_DBG_N) { dbg_lds[dbg_i] = (long long)__builtin_readcyclecounter(); ++dbg_i; } \
+    } while (0)
+#else
+#define HS_DBG_LDS 0
+#define HS_STAMP() do {} while (0)
+#endif
 
 template <int K>
 using hs_ic = std::integral_constant<int, K>;
@@ -42,8 +57,13 @@ __device__ __forceinline__ int hs_b_off(int row, int stage, int piece) {
 }
 
 // NPA: halo pieces (1 KiB = 8 pixel rows of 128 B) per wave and channel chunk; the halo buffer holds 64 NPA rows >= 256 + 2 (W + 1)
-template <int NPA>
+// EB:  "early barrier" — how many of a matrix phase's 24 MFMAs are issued AFTER the barrier that ends it (0, 4 or 8).  The phase timeline
+//      (tools/halo_timeline.py) shows the matrix pipe idle for ~130 cycles at every hand-over: the finishing wave reaches the barrier, the barrier
+//      releases, the partner wakes up and issues its first MFMA.  With the barrier placed EB MFMAs before the end, the finishing wave's tail keeps the
+//      pipe busy while the partner wakes up.  Nothing the barrier orders depends on the position of a wave's MFMAs (they only touch registers).
+template <int NPA, int EB>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
+    constexpr int NL = 3;   // DMA instructions issued in the load phase: 1-3 measured equal, 0 (all among the MFMAs) 2-3 % slower (profiles/r03b_halo_nl_sweep.txt)
     extern __shared__ __attribute__((aligned(16))) float hs_smem[];
     char* lds = (char*)hs_smem;
     constexpr int ABUF = NPA * 8 * 1024;                            // one halo buffer
@@ -60,37 +80,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
     const int W = d.W, HW = d.H * d.W;
     const int fr = lane & 31, hb = lane >> 5;
 
+#ifdef SMIRK_DEBUG_HOOKS
+    const int dbg_slot = (blockIdx.x % 97 == 0) ? (int)(blockIdx.x / 97) : -1;
+    const bool dbg_on = g_hs_dbg != nullptr && dbg_slot >= 0 && dbg_slot < 8 && (tid == 0 || tid == 256);
+    long long* dbg_lds = (long long*)(lds + A0 + 2 * ASTRIDE) + (tid >> 8) * HS_DBG_N;
+    int dbg_i = 0;
+    const long long dbg_t_entry = (long long)__builtin_readcyclecounter();
+#endif
     // ---- zero rows (read by every tap that falls into the zero padding) ------------------------------------------------------------------------
     if (tid < 64) *(float*)(lds + A0 + (tid >> 5) * ASTRIDE + ABUF + (tid & 31) * 4) = 0.f;
 
-    // ---- per-lane tap table: LDS byte offset (inside a halo buffer) of the (k-step 0, hi) piece of this lane's A row for each tap; rows i = 0 / 1
-    //      of the wave tile in the low / high 16 bits.  The other three pieces of a row are offset ^ 16 (lo), ^ 64 (k-step 1), ^ 80. --------------
-    unsigned tabA[9];
-    {
-        unsigned ent[2][9];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rl = (wm * 2 + i) * 32 + fr;
-            const int m = m0 + rl;
-            const int b = m / HW, rem = m - b * HW, y = rem / W, x = rem - y * W;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                int dy = t / 3 - 1, dx = t % 3 - 1;
-                bool zero = m >= a.M;
-                if (d.pad_mode == SMIRK_PAD_REFLECT) {
-                    if (y + dy < 0 || y + dy >= d.H) dy = -dy;
-                    if (x + dx < 0 || x + dx >= W) dx = -dx;
-                } else {
-                    zero = zero || y + dy < 0 || y + dy >= d.H || x + dx < 0 || x + dx >= W;
-                }
-                const int p = rl + (W + 1) + dy * W + dx;         // halo row
-                const unsigned off = (unsigned)p * 128u + (unsigned)(((2 * hb) ^ ((p >> 1) & 7)) << 4);
-                ent[i][t] = zero ? (unsigned)ABUF : off;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) tabA[t] = ent[0][t] | (ent[1][t] << 16);
-    }
+    unsigned tabA[9];                                              // per-lane tap table, filled in the prologue while the first DMAs fly
     // B fragment bases: (k-step 0, hi) piece of rows (wn*2 + j)*32 + fr in stage 0
     unsigned bB[2];
 #pragma unroll
@@ -128,13 +128,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
         if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (hs_lptr_t)dst, 16, vo, so, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (hs_lptr_t)dst, 16, vo, so, 0, 0);
     };
-    // weight chunk (cc, TAP) -> ring stage ST: 2 pieces per wave
-    auto dmaB = [&](int cc, auto tapc, auto stc) {
-        constexpr int TAP = decltype(tapc)::value, ST = decltype(stc)::value;
+    // weight chunk (cc, TAP) -> ring stage ST: piece P (of 2) of this wave
+    auto dmaB1 = [&](int cc, auto tapc, auto stc, auto pc) {
+        constexpr int TAP = decltype(tapc)::value, ST = decltype(stc)::value, P = decltype(pc)::value;
         const int so = (TAP * a.Cin + cc * CV_BK) * 4;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (hs_lptr_t)(lds + (((swave + 8 * p) * HS_NSTAGE + ST) << 10)), 16, voffB[p], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (hs_lptr_t)(lds + (((swave + 8 * P) * HS_NSTAGE + ST) << 10)), 16, voffB[P], so, 0, 0);
+    };
+    auto dmaB = [&](int cc, auto tapc, auto stc) {
+        dmaB1(cc, tapc, stc, hs_ic<0>{});
+        dmaB1(cc, tapc, stc, hs_ic<1>{});
     };
 
     f32x16 acc0[2][2], acc1[2][2];
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
     auto body = [&](int cc, int acur, int anext, auto tapc) {
         constexpr int TAP = decltype(tapc)::value, ST = TAP % 3;
         // ---- load phase ------------------------------------------------------------------------------------------------------------------------
+        HS_STAMP();
         {
             const unsigned t = tabA[TAP];
             const unsigned a0 = (t & 0xffffu) + (unsigned)acur, a1 = (t >> 16) + (unsigned)acur;
@@ -164,48 +167,75 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
                 bh[1][j] = *(const half8*)(lds + (b0 ^ 64u) + ST * 1024);  bl[1][j] = *(const half8*)(lds + (b0 ^ 80u) + ST * 1024);
             }
         }
-        // halo piece TAP of the NEXT channel chunk (past the end of K the clamped last chunk is fetched again into the buffer nobody reads), then
-        // the weight chunk two ahead
-        if constexpr (TAP < NPA) dmaA(min(cc + 1, ncc - 1), anext, hs_ic<TAP>{});
+        // this phase pair's DMA list: [halo piece TAP of the NEXT channel chunk (taps 0 .. NPA-1),] the two weight pieces of the chunk two ahead.  Past
+        // the end of K the clamped last chunk is fetched again into a buffer / stage nobody reads: no branch in the loop bodies.
         constexpr int T2 = (TAP + 2) % 9;
-        dmaB(min(cc + (TAP + 2 >= 9 ? 1 : 0), ncc - 1), hs_ic<T2>{}, hs_ic<T2 % 3>{});
-        // everything older than this phase's DMA instructions has landed (this wave's share of chunk q+1's weights, and every halo piece issued
+        constexpr int HASA = TAP < NPA ? 1 : 0, NDMA = 2 + HASA, NLD = NL < NDMA ? NL : NDMA;
+        const int ccA = min(cc + 1, ncc - 1), ccB = min(cc + (TAP + 2 >= 9 ? 1 : 0), ncc - 1);
+        auto dma = [&](auto kc) {                                    // DMA instruction K of the list
+            constexpr int K = decltype(kc)::value;
+            if constexpr (HASA && K == 0) dmaA(ccA, anext, hs_ic<(TAP < NPA ? TAP : 0)>{});
+            else dmaB1(ccB, hs_ic<T2>{}, hs_ic<T2 % 3>{}, hs_ic<K - HASA>{});
+        };
+        if constexpr (NLD > 0) dma(hs_ic<0>{});
+        if constexpr (NLD > 1) dma(hs_ic<1>{});
+        if constexpr (NLD > 2) dma(hs_ic<2>{});
+        // everything older than this load phase's DMA instructions has landed (this wave's share of chunk q+1's weights, and every halo piece issued
         // in an earlier phase); fragment reads done
-        if constexpr (TAP < NPA) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        if constexpr (NLD == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NLD == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if constexpr (NLD == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HS_STAMP();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- matrix phase: 24 MFMAs, operands in registers; dependent accumulations four instructions apart -------------------------------------
+        HS_STAMP();
+        // ---- matrix phase: 24 MFMAs, operands in registers; dependent accumulations four instructions apart; the DMA instructions left over from
+        //      the load phase go out one after every fourth MFMA (an LDS-DMA costs ~60 issue cycles among bare MFMAs, MI355X_MICROARCH.md) ---------
         __builtin_amdgcn_s_setprio(1);
+        auto mm_dma = [&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            if constexpr (NLD + G < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma(hs_ic<(NLD + G < NDMA ? NLD + G : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto mblock = [&](auto bc) {                                 // MFMA block B (0-5) of the chunk: 4 independent accumulators
+            constexpr int BK = decltype(bc)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], acc0[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], acc1[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], acc1[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], acc0[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], acc1[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], acc1[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (BK == 0) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], acc0[i][j], 0, 0, 0);
+                    if constexpr (BK == 1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 2) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 3) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], acc0[i][j], 0, 0, 0);
+                    if constexpr (BK == 4) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 5) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], acc1[i][j], 0, 0, 0);
+                }
+        };
+        auto hand_over = [&]() {                                     // the barrier that ends the matrix phase
+            HS_STAMP();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        mblock(hs_ic<0>{});
+        mm_dma(hs_ic<0>{});
+        mblock(hs_ic<1>{});
+        mm_dma(hs_ic<1>{});
+        mblock(hs_ic<2>{});
+        mm_dma(hs_ic<2>{});
+        mblock(hs_ic<3>{});
+        if constexpr (EB == 8) hand_over();
+        mblock(hs_ic<4>{});
+        if constexpr (EB == 4) hand_over();
+        mblock(hs_ic<5>{});
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (EB == 0) hand_over();
+        else __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue: the halo of chunk 0 and weight chunks 0 and 1 in flight, everything but weight chunk 1 landed; group 1 drops one phase behind ----
@@ -213,6 +243,34 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
     if constexpr (NPA > 5) dmaA(0, A0, hs_ic<5>{});
     dmaB(0, hs_ic<0>{}, hs_ic<0>{});
     dmaB(0, hs_ic<1>{}, hs_ic<1>{});
+    __builtin_amdgcn_sched_barrier(0);                             // the first operands are in flight while the tap table (4 integer divisions) is computed
+    // ---- per-lane tap table: LDS byte offset (inside a halo buffer) of the (k-step 0, hi) piece of this lane's A row for each tap; rows i = 0 / 1
+    //      of the wave tile in the low / high 16 bits.  The other three pieces of a row are offset ^ 16 (lo), ^ 64 (k-step 1), ^ 80. --------------
+    {
+        unsigned ent[2][9];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = (wm * 2 + i) * 32 + fr;
+            const int m = m0 + rl;
+            const int b = m / HW, rem = m - b * HW, y = rem / W, x = rem - y * W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                int dy = t / 3 - 1, dx = t % 3 - 1;
+                bool zero = m >= a.M;
+                if (d.pad_mode == SMIRK_PAD_REFLECT) {
+                    if (y + dy < 0 || y + dy >= d.H) dy = -dy;
+                    if (x + dx < 0 || x + dx >= W) dx = -dx;
+                } else {
+                    zero = zero || y + dy < 0 || y + dy >= d.H || x + dx < 0 || x + dx >= W;
+                }
+                const int p = rl + (W + 1) + dy * W + dx;         // halo row
+                const unsigned off = (unsigned)p * 128u + (unsigned)(((2 * hb) ^ ((p >> 1) & 7)) << 4);
+                ent[i][t] = zero ? (unsigned)ABUF : off;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tabA[t] = ent[0][t] | (ent[1][t] << 16);
+    }
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -224,12 +282,40 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
         body(cc, acur, anext, hs_ic<6>{}); body(cc, acur, anext, hs_ic<7>{}); body(cc, acur, anext, hs_ic<8>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the over-fetched pieces must have landed before LDS is reused
+    // ---- epilogue operands, requested BEFORE the closing barriers so that the loads fly while the workgroup drains ------------------------------
+    // Every lane serves ONE 8-channel group (g = lane % 8) of 4 pixel rows per 32-row block: scale / shift are loaded once, and all eight residual
+    // groups (2 blocks x 4 rows) are requested up front: the epilogue pays one memory round trip, not one per block (the fragment registers are free now).
+    float* ebuf = hs_smem + wave * 32 * HS_EPI_LD;
+    constexpr int GPR = 8, ITEMS = 32 * GPR / 64;
+    const int eg = lane & 7, erow = lane >> 3;                       // item = it * 64 + lane: row = it * 8 + erow, group = eg
+    const int en = n0 + wn * 64 + eg * 8;
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sf0 = {0.f, 0.f, 0.f, 0.f}, sf1 = sf0;
+    if (a.scale) { sc0 = *(const f32x4*)(a.scale + en); sc1 = *(const f32x4*)(a.scale + en + 4); }
+    if (a.shift) { sf0 = *(const f32x4*)(a.shift + en); sf1 = *(const f32x4*)(a.shift + en + 4); }
+    half8 resh[2][ITEMS], resl[2][ITEMS];
+    if (a.residual) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int m = min(m0 + (wm * 2 + i) * 32 + it * 8 + erow, a.M - 1);
+                const size_t o = (size_t)m * d.Cout + en;
+                resh[i][it] = *(const half8*)(a.residual + o);
+                resl[i][it] = *(const half8*)(a.residual + o + 4);
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (group == 0) __builtin_amdgcn_s_barrier();                   // both groups have executed the same number of barriers ...
     __builtin_amdgcn_s_barrier();                                   // ... and every wave's DMA has retired
 
-    // ---- epilogue (conv_pp.hip's): per-wave transpose through LDS, whole 8-channel groups, BN scale/shift + residual + ReLU, re-split ---------
-    float* ebuf = hs_smem + wave * 32 * HS_EPI_LD;
-    constexpr int GPR = 8, ITEMS = 32 * GPR / 64;
+#ifdef SMIRK_DEBUG_HOOKS
+    HS_STAMP();
+    if (dbg_on)
+        for (int k = 0; k < dbg_i; ++k) g_hs_dbg[(dbg_slot * 2 + (tid >> 8)) * HS_DBG_N + k] = dbg_lds[k];
+    __builtin_amdgcn_s_barrier();
+#endif
+    // ---- epilogue: per-wave transpose through LDS, whole 8-channel groups, BN scale/shift + residual + ReLU, re-split ---------------------------
+    HS_STAMP();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -239,27 +325,24 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            const int item = it * 64 + lane, row = item / GPR, g = item % GPR;
-            const int m = m0 + (wm * 2 + i) * 32 + row, n = n0 + wn * 64 + g * 8;
-            if (m < a.M && n < a.N) {
+            const int row = it * 8 + erow;
+            const int m = m0 + (wm * 2 + i) * 32 + row;
+            if (m < a.M) {
                 float v[8];
-                *(f32x4*)v = *(const f32x4*)(ebuf + row * HS_EPI_LD + g * 8);
-                *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * HS_EPI_LD + g * 8 + 4);
-                const size_t o = (size_t)m * d.Cout + n;             // raster order: GEMM row m IS the NHWC pixel index
+                *(f32x4*)v = *(const f32x4*)(ebuf + row * HS_EPI_LD + eg * 8);
+                *(f32x4*)(v + 4) = *(const f32x4*)(ebuf + row * HS_EPI_LD + eg * 8 + 4);
+                const size_t o = (size_t)m * d.Cout + en;            // raster order: GEMM row m IS the NHWC pixel index
                 if (a.scale) {
-                    const f32x4 s0 = *(const f32x4*)(a.scale + n), s1 = *(const f32x4*)(a.scale + n + 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { v[q] *= s0[q]; v[4 + q] *= s1[q]; }
+                    for (int q = 0; q < 4; ++q) { v[q] *= sc0[q]; v[4 + q] *= sc1[q]; }
                 }
                 if (a.shift) {
-                    const f32x4 s0 = *(const f32x4*)(a.shift + n), s1 = *(const f32x4*)(a.shift + n + 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { v[q] += s0[q]; v[4 + q] += s1[q]; }
+                    for (int q = 0; q < 4; ++q) { v[q] += sf0[q]; v[4 + q] += sf1[q]; }
                 }
                 if (a.residual) {
-                    const half8 rh = *(const half8*)(a.residual + o), rl = *(const half8*)(a.residual + o + 4);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += join1(rh[q], rl[q]);
+                    for (int q = 0; q < 8; ++q) v[q] += join1(resh[i][it][q], resl[i][it][q]);
                 }
                 if (d.act == SMIRK_ACT_RELU) {
 #pragma unroll
@@ -273,6 +356,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#ifdef SMIRK_DEBUG_HOOKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HS_STAMP();
+    if (dbg_on) {
+        long long* g = g_hs_dbg + (dbg_slot * 2 + (tid >> 8)) * HS_DBG_N;
+        g[HS_DBG_N - 3] = dbg_lds[dbg_i - 2]; g[HS_DBG_N - 2] = dbg_lds[dbg_i - 1]; g[HS_DBG_N - 4] = dbg_t_entry;
+    }
+#endif
 }
 
 static int hs_env_mode() {                                           // $SMIRK_IGEMM_HALO: "0" off, "all" every eligible geometry, unset = measured default
@@ -291,20 +382,19 @@ bool smirk_conv_halo_eligible(const ConvArgs& a) {
     if (a.N % HS_BN || a.N < HS_BN) return false;
     const long long b0 = (long long)d.B * d.H * d.W * d.C0 * 4, b1 = (long long)d.B * d.H * d.W * d.C1 * 4, bw = (long long)a.N * a.K * 4;
     if (b0 >= (1ll << 31) || b1 >= (1ll << 31) || bw >= (1ll << 31)) return false;
-    if (mode != 2 && (long long)d.Ho * d.Wo > HS_DEFAULT_MAX_PIXELS) return false;
-    return a.M >= 4 * HS_BM;                                          // tiny problems stay on the 128-row tiles
+    if (a.M < 4 * HS_BM) return false;                               // tiny problems stay on the 128-row tiles
+    // Measured per layer against the kernels it replaces (tools/conv_sweep.py, profiles/r03c_halo_sweep.txt): at 1024 frames per pass every deep
+    // layer gains 12-18 % (14x14: 421 -> 502-513 TFLOP/s, 28x28: 405-420 -> 487-523, 56x56: 361-398 -> 431-483); at 128 frames the layers with
+    // K >= 2304 gain 3-13 % and the short-K layers (18-36 chunks per tile: the lone workgroup's prologue / epilogue are exposed) lose up to 8 %.
+    const long long tiles = ((long long)a.M + HS_BM - 1) / HS_BM * (a.N / HS_BN);
+    return mode == 2 || a.K >= 2304 || tiles >= 2048;
 }
 
-int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st) {
-    const int npa = (HS_BM + 2 * (a.d.W + 1) + 63) / 64;             // 64 halo rows per piece index (8 waves x 8 rows)
-    const size_t lds = HS_BRING_BYTES + 2 * ((size_t)(npa <= 5 ? 5 : 6) * 8 * 1024 + 128);
+template <int NPA, int EB>
+static int hs_launch(const ConvArgs& a, hipStream_t st, size_t lds, int dev) {
     static bool attr_done[64] = {};                                  // hipFuncSetAttribute is per-device state (one process may drive several GPUs)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_halo_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<NPA, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SMIRK_ERR_LAUNCH;
         attr_done[dev] = true;
     }
@@ -312,11 +402,39 @@ int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st) {
     if (g_smirk_prof_on) {
         const double px = (double)a.d.B * a.d.H * a.d.W;
         char nm[64];
-        snprintf(nm, sizeof(nm), "conv_halo_kernel<%d>[256x128,8w,halo]", npa <= 5 ? 5 : 6);
+        snprintf(nm, sizeof(nm), "conv_halo_kernel<%d,%d>[256x128,8w,halo]", NPA, EB);
         smirk_prof_next(nm, 2.0 * a.M * a.N * a.K,
                         4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
     }
-    if (npa <= 5) SMIRK_LAUNCH(conv_halo_kernel<5>, dim3(ntm * ntn), dim3(512), lds, st, a);
-    else SMIRK_LAUNCH(conv_halo_kernel<6>, dim3(ntm * ntn), dim3(512), lds, st, a);
+    SMIRK_LAUNCH((conv_halo_kernel<NPA, EB>), dim3(ntm * ntn), dim3(512), lds, st, a);
     return smirk_launch_status();
+}
+
+int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st) {
+    const int npa = (HS_BM + 2 * (a.d.W + 1) + 63) / 64;             // 64 halo rows per piece index (8 waves x 8 rows)
+    const size_t lds = HS_BRING_BYTES + 2 * ((size_t)(npa <= 5 ? 5 : 6) * 8 * 1024 + 128) + HS_DBG_LDS;
+#ifdef SMIRK_DEBUG_HOOKS
+    {
+        const char* e = getenv("SMIRK_HALO_DBG");                   // hex device address of a zeroed int64 buffer [8][2][HS_DBG_N], tools/halo_timeline.py
+        long long* p = e ? (long long*)strtoull(e, nullptr, 16) : nullptr;
+        if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_hs_dbg), &p, sizeof(p), 0, hipMemcpyHostToDevice, st) != hipSuccess) return SMIRK_ERR_LAUNCH;
+    }
+#endif
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
+    const char* ebe = getenv("SMIRK_HALO_EB");                       // tuning switch: MFMAs issued after the hand-over barrier (0, 4, 8)
+    const int eb = ebe ? atoi(ebe) : HS_DEFAULT_EB;
+    if (npa <= 5) {
+        switch (eb) {
+            case 0: return hs_launch<5, 0>(a, st, lds, dev);
+            case 8: return hs_launch<5, 8>(a, st, lds, dev);
+            default: return hs_launch<5, 4>(a, st, lds, dev);
+        }
+    }
+    switch (eb) {
+        case 0: return hs_launch<6, 0>(a, st, lds, dev);
+        case 8: return hs_launch<6, 8>(a, st, lds, dev);
+        default: return hs_launch<6, 4>(a, st, lds, dev);
+    }
 }

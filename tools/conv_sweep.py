@@ -75,9 +75,13 @@ if __name__ == "__main__":
             extra = f"   [PP off: {ms0:8.3f} ms {tf0:7.1f} TFLOP/s]"
         if a.ab_env:
             k_, v_ = a.ab_env.split("=", 1)
+            old_ = os.environ.get(k_)
             os.environ[k_] = v_
             ms0, tf0 = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
-            del os.environ[k_]
+            if old_ is None:
+                del os.environ[k_]
+            else:
+                os.environ[k_] = old_
             extra = f"   [{a.ab_env}: {ms0:8.3f} ms {tf0:7.1f} TFLOP/s]"
         ms, tf = run(B, H, C0, C1, Cout, k, convt, refl, a.iters, a.mode == "f16x3")
         tot_ms += ms * cnt; tot_fl += tf * ms * cnt
