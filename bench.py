@@ -762,10 +762,6 @@ def main():
             "path_tflops_per_gpu": value / world * flop_face / 1e12,
             "path_frac_of_f16_mfma_peak": value / world * flop_face / PEAK_F16_MFMA,
             "output_stats": stats, "roofline": roof, "cpu_baseline": cpu}
-        if args.workload == "train64":                            # the one-launch BatchNorm's grid barriers must never have timed out (include/smirk_hip.h)
-            from smirk_amd import _lib as L
-            line["bn_fused_barrier_timeouts"] = int(L.lib().smirk_bn_fused_errors())
-            assert line["bn_fused_barrier_timeouts"] == 0, "a cooperative BatchNorm grid was not fully resident: results invalid"
         if args.plumbing_test:
             line["plumbing"] = {"gathered_ids_last": wl.seen[-1], "micro_batches_per_step": len(wl.slices), "gathers": len(wl.seen)}
         print(json.dumps(line), flush=True)

@@ -285,6 +285,15 @@ int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_
  * scale / shift.  The expanded tensors never leave the CU's LDS.  All channel counts must be multiples of 8. */
 size_t smirk_mbconv_lds_bytes(int Cin, int mid, int Cout, int stride);
 /* 1 if the fused kernel serves this block shape (Cin <= 48, Cout <= 96, LDS <= 64 KiB); otherwise use the per-layer kernels */
+/* Stem + first DepthwiseSeparable block of a MobileNetV3-minimal backbone in ONE launch (timm `conv_stem` + `bn1` + `blocks[0][0]`; reference call site
+ * src/smirk_encoder.py:18-21,52-55,80-83 `self.encoder(img)[-1]`): img[B][3][H][W] NCHW fp32 -> 3x3 s2 conv 3->16 + BN + ReLU -> 3x3 depthwise (stride 1 | 2,
+ * TF-SAME) + BN + ReLU -> 1x1 16->16 + BN (+ the stem output when residual) -> out split16 NHWC [B][Ho][Wo][16].  stem_w [16][27] fp32 (k = (ky,kx,c)),
+ * dw_w [9][16] fp32, pw_w split16 rows [16][16]; scales / shifts are folded eval-mode BatchNorm.  smirk_encoder_head_supported: 1 when the backbone's
+ * stem / first block have that shape (the caller keeps the three-launch sequence otherwise). */
+int smirk_encoder_head_supported(int stem_cout, int kind, int cin, int mid, int cout, int stride, int skip);
+int smirk_encoder_head_fused_split16(const float* img, const float* stem_w, const float* stem_scale, const float* stem_shift, const float* dw_w,
+                                     const float* dw_scale, const float* dw_shift, const void* pw_w, const float* pw_scale, const float* pw_shift,
+                                     int residual, void* out, int B, int H, int W, int stride, void* stream);
 int smirk_mbconv_supported(int Cin, int mid, int Cout, int stride);
 int smirk_mbconv_fused_split16(const void* x, const void* wexp, const float* s1, const float* b1, const float* wdw, const float* s2,
                                const float* b2, const void* wproj, const float* s3, const float* b3, int residual, void* out,
@@ -369,13 +378,6 @@ int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* 
 /* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
 int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
-/* Opt-in: tensors up to 64 MB can run forward / backward BatchNorm as ONE cooperative launch (partial sums, finalisation and the element-wise pass separated by grid
- * barriers; same arithmetic and summation order inside each stage as the three-launch form used above that size).  smirk_bn_set_fused(0 / 1 / -1) forces the
- * three-launch form / the one-launch form / $SMIRK_BN_FUSED (default OFF: measured slower on MI355X) and returns the previous setting; smirk_bn_fused_errors() synchronises the device and
- * returns the number of streams on which a grid barrier ever timed out (a grid that was not fully resident; results of that call are then invalid) — 0 always
- * in the tests and benchmarks. */
-int smirk_bn_set_fused(int on);
-int smirk_bn_fused_errors(void);
 /* sums[c] = sum over the M rows of x[.][c]  (bias gradients) */
 int smirk_colsum_split16(const void* x, size_t M, int C, float* sums, void* ws, size_t ws_bytes, void* stream);
 /* nn.MaxPool2d(2, 2) backward: dx[b,2y+i,2x+j,c] = dy[b,y,x,c] at the first maximum of the window (ATen scan order), 0 elsewhere, + add (nullable:

@@ -90,6 +90,8 @@ _SIGS = {
     "smirk_render_backward_workspace_bytes": (_sz, [C.POINTER(SmirkRenderMesh), _i, _i, _i]),
     "smirk_render_backward": (_i, [C.POINTER(SmirkRenderMesh), _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_project_landmarks_backward": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
+    "smirk_encoder_head_supported": (_i, [_i] * 7),
+    "smirk_encoder_head_fused_split16": (_i, [_p] * 10 + [_i, _p] + [_i] * 4 + [_p]),
     "smirk_mbconv_lds_bytes": (_sz, [_i, _i, _i, _i]),
     "smirk_mbconv_supported": (_i, [_i, _i, _i, _i]),
     "smirk_mbconv_fused_split16": (_i, [_p] * 10 + [_i, _p] + [_i] * 7 + [_p]),
@@ -130,8 +132,6 @@ _SIGS = {
     "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
     "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
-    "smirk_bn_set_fused": (_i, [_i]),
-    "smirk_bn_fused_errors": (_i, []),
     "smirk_colsum_split16": (_i, [_p, _sz, _i, _p, _p, _sz, _p]),
     "smirk_maxpool2x2_backward_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_reflect_pad1_backward_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

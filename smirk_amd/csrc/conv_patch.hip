@@ -651,8 +651,12 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
     PatchArgs a;
     a.fw = fw; a.fb = fb; a.fout = fout; a.fcout = fcout;
     {   // debugging aid: SMIRK_PATCH_DBG=<device address (hex) of a zeroed int64 buffer of >= 8*48*6 entries>, see tools/patch_timeline.py
+#ifdef SMIRK_DEBUG_HOOKS                                                 /* a raw device address from the environment: variant builds only */
         const char* e = getenv("SMIRK_PATCH_DBG");
         a.dbg = e ? (long long*)strtoull(e, nullptr, 16) : nullptr;
+#else
+        a.dbg = nullptr;
+#endif
     }
     a.in0 = (const float*)in0; a.in1 = (const float*)in1; a.w = (const float*)w; a.scale = scale; a.shift = shift; a.out = (float*)out;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout; a.act = d->act;
@@ -671,14 +675,20 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
                         px * (d->C0 + d->C1) * 4.0 + outb + K * d->Cout * 4.0);
     }
     if (!patch_resident(d)) {
-        static bool attr2 = false;
+        static bool attr2_dev[64] = {};                              // per device ordinal (hipFuncSetAttribute is per-device state)
+        int dev2 = 0;
+        (void)hipGetDevice(&dev2);
+        bool& attr2 = attr2_dev[(dev2 >= 0 && dev2 < 64) ? dev2 : 0];
         if (!attr2) { (void)hipFuncSetAttribute((const void*)conv3x3_patch_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
         const size_t lds2 = (size_t)(2 * WSTAGE + 2 * PSTAGE) * 4;
         SMIRK_LAUNCH(conv3x3_patch_stream_kernel, dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), lds2, st, a);
         return smirk_launch_status();
     }
     const size_t wbytes = (size_t)a.nchunk * 9 * d->Cout * 32 * 4;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};                              // per device ordinal (hipFuncSetAttribute is per-device state)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& attr_done = attr_done_dev[(dev >= 0 && dev < 64) ? dev : 0];
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -121,13 +121,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
             if constexpr (KX == 2) px += 1 - (int)((f >> 3) & 1u) * 2;
             const unsigned inval = (((f >> (4 + KY)) & (f >> (7 + KX))) & 1u) ^ 1u;    // 1: this tap of this row lies in the zero padding
             vo[p] = (((unsigned)px << sh) + col16) | (inval << 31);                    // bit 31 set => beyond num_records => the DMA writes zeros
+#ifdef SMIRK_DEBUG_HOOKS
             if (a.ablate == 1) vo[p] = (unsigned)(tid & 63) * 16u;                    // timing experiment only: every A piece re-reads one L1-resident KiB
+#endif
         }
     };
     auto piece = [&](auto kc, auto stc) {
         constexpr int KP = decltype(kc)::value, ST = decltype(stc)::value;
         if constexpr (KP < 4) {
+#ifdef SMIRK_DEBUG_HOOKS
             if (a.ablate == 2) return;                                               // timing experiment only: no A traffic at all
+#endif
             float* dst = smem + (((swave + 8 * KP) * PP_NSTAGE + ST) << 8);          // block swave + 8 KP (rows 8 swave + 64 KP ...), stage ST
             if (dma_s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (pp_lptr_t)dst, 16, vo[KP], dma_sa, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (pp_lptr_t)dst, 16, vo[KP], dma_sa, 0, 0);
@@ -326,7 +330,11 @@ bool smirk_conv_pp_eligible(const ConvArgs& a) {
 }
 
 int smirk_conv_pp_launch(const ConvArgs& a_in, hipStream_t st) {
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};                              // hipFuncSetAttribute is per-device state: one flag per device ordinal
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
+    bool& attr_done = attr_done_dev[dev];
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)conv_pp_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
@@ -336,7 +344,9 @@ int smirk_conv_pp_launch(const ConvArgs& a_in, hipStream_t st) {
         attr_done = true;
     }
     ConvArgs a = a_in;
+#ifdef SMIRK_DEBUG_HOOKS                                                 /* -DSMIRK_DEBUG_HOOKS variant builds only (tools/build_variant.sh) */
     if (const char* ab = getenv("SMIRK_PP_ABLATE")) a.ablate = atoi(ab);        // WRONG RESULTS: operand-traffic timing experiments
+#endif
     const char* nle = getenv("SMIRK_PP_NL");                         // tuning switch: DMA instructions issued in the load phase (default 3)
     const int nl = nle ? atoi(nle) : 3;
     const int ntm = (a.M + PP_BM - 1) / PP_BM, ntn = a.N / PP_BN;

@@ -243,6 +243,19 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
     const bool no_fuse = getenv("SMIRK_DISABLE_MBCONV_FUSED") != nullptr, fuse_ds = getenv("SMIRK_MBCONV_FUSE_DS") != nullptr;   // A/B switches (tests)
     int h = (H + 1) / 2, wd = (W + 1) / 2;
     void* x = p.rot.slot[0];
+    // stem + first DepthwiseSeparable block in one launch (encoder_head.hip): the 16-channel 112 x 112 tensors between them never reach HBM
+    int first_block = 0;
+    {
+        const SmirkMbBlock& b0 = w->blocks[0];
+        const bool no_head = getenv("SMIRK_DISABLE_ENCODER_HEAD_FUSED") != nullptr;                                               // A/B switch (tests)
+        if (split && !no_head && smirk_encoder_head_supported(w->stem_cout, b0.kind, b0.cin, b0.mid, b0.cout, b0.stride, b0.skip)) {
+            TRY(smirk_encoder_head_fused_split16(img, (const float*)w->stem.w, w->stem.scale, w->stem.shift, (const float*)b0.dw.w, b0.dw.scale, b0.dw.shift,
+                                                 b0.pw.w, b0.pw.scale, b0.pw.shift, b0.skip ? 1 : 0, x, B, H, W, b0.stride, stream));
+            h = (h + b0.stride - 1) / b0.stride; wd = (wd + b0.stride - 1) / b0.stride;
+            first_block = 1;
+        }
+    }
+    if (!first_block)
     TRY(split ? smirk_stem_conv_s2_split16(img, (const float*)w->stem.w, w->stem.scale, w->stem.shift, x, B, H, W, w->stem_cout, stream)
               : smirk_stem_conv_s2(img, (const float*)w->stem.w, w->stem.scale, w->stem.shift, (float*)x, B, H, W, w->stem_cout, stream));
     auto pointwise = [&](const void* in, int hh, int ww, int cin, int cout, const SmirkConvLayer& L, bool relu, const void* res, void* o) {
@@ -252,8 +265,8 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
         return split ? smirk_dwconv3x3_split16(in, (const float*)L.w, L.scale, L.shift, o, B, hh, ww, c, stride, 1, stream)
                      : smirk_dwconv3x3((const float*)in, (const float*)L.w, L.scale, L.shift, (float*)o, B, hh, ww, c, stride, 1, stream);
     };
-    int c = w->stem_cout;
-    for (int i = 0; i < w->n_blocks; ++i) {
+    int c = first_block ? w->blocks[0].cout : w->stem_cout;
+    for (int i = first_block; i < w->n_blocks; ++i) {
         const SmirkMbBlock& b = w->blocks[i];
         if (b.cin != c) return SMIRK_ERR_BAD_ARG;
         const int ho = (h + b.stride - 1) / b.stride, wo = (wd + b.stride - 1) / b.stride;

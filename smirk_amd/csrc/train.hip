@@ -49,10 +49,9 @@ inline unsigned blocks_for(size_t items, unsigned cap) {
 //   MODE 1 (BN backward)     f = dyh,          g = dyh * xhat      with dyh = dy * [relu ? (xhat*gamma+beta > 0) : 1], xhat = (z-mean)*invstd
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define RED_BLOCKS 512
-// Device-coherent accesses for the few values workgroups of ONE launch hand to each other (bn_fused_kernel): relaxed agent-scope atomics are issued with the
-// cache-coherence bits set (write-through / read-through the per-XCD L2), so no fence is needed to make them visible across the eight XCDs.  The generic
-// alternative — __threadfence() = agent-scope release / acquire — writes back and invalidates the XCD's whole L2 on this part: a grid barrier built on it
-// cost ~150 us (measured: 331 us per one-launch BatchNorm against ~40 us for three dependent launches, gpurun_out/r02ah).
+// DEV = true: device-coherent accesses (relaxed agent-scope atomics) for values that workgroups of ONE launch hand to each other.  Unused by the shipped
+// three-launch BatchNorm; the one-launch cooperative form that needed it was measured slower on this 8-XCD part (a grid barrier costs 15-20 us, a dependent
+// launch less: DESIGN.md 8.9, profiles/r02ai_bn_one_launch_experiment.txt) and was removed from the library in round 3 (git history: train.hip @ 9afbeda).
 template <bool DEV, typename T>
 __device__ __forceinline__ void st_x(T* p, T v) {
     if (DEV) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -254,85 +253,6 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
                                                                 const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, int relu,
                                                                 float* __restrict__ dz) {
     bn_backward_apply_body(z, dy, M, G, inv_n, mean, invstd, gamma, beta, sum_dy, sum_dy_xhat, relu, dz);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// One-launch BatchNorm (EXPERIMENT, opt-in: $SMIRK_BN_FUSED=1 / smirk_bn_set_fused): the 279 BatchNorm calls of a training step spend 3.7 ms in finalisation
-// kernels that are pure launch gap, so a grid of <= 256 co-resident workgroups runs the SAME three stages — partial sums (colsum_partial), finalisation of 16
-// channels per workgroup (stage2_sum's fixed order), element-wise pass — in one launch, separated by two grid barriers: an arrival counter in device memory,
-// device-coherent (cache-bypassing) accesses for the handful of values that cross workgroups instead of fences, a bounded spin (a grid that for any reason is
-// not fully resident raises a sticky error word instead of hanging the GPU; smirk_bn_fused_errors).  Counters are library-owned, one set per stream, and
-// reset by the last workgroup to leave.  Correct (tests/test_train_ops_gpu.py runs both forms) but SLOWER on MI355X, which is why it is not the default:
-//   * with __threadfence() (agent-scope release / acquire) a barrier writes back and invalidates the XCD's L2: 331 us per call (three launches: ~47 us);
-//   * with relaxed agent-scope atomics (sc1 loads / stores, no fences) 85 us per forward call, 71 us per backward call — a barrier across the eight XCDs
-//     still costs 15-20 us, and 256 workgroups stream the two data passes far below what the 2048-workgroup kernels reach.  train64: 52.6 vs 45.6 ms.
-// ---------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool grid_barrier(unsigned* cnt, unsigned target, int* flag_lds) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's device-coherent stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 0;
-        for (int it = 0; it < (1 << 21); ++it) {
-            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        *flag_lds = ok;
-    }
-    __syncthreads();
-    return *flag_lds != 0;
-}
-
-struct BnFusedArgs {
-    const float *z, *dy;                                    // dy: backward only
-    size_t M;
-    int G, relu;
-    const float *gamma, *beta, *residual;
-    float eps, momentum;
-    float *mean, *var, *invstd, *running_mean, *running_var;   // forward: written; backward: mean / invstd are read
-    float *out;                                             // y (forward) / dz (backward)
-    float *dgamma, *dbeta;
-    double* part;
-    unsigned* sync;                                         // [0], [1] barrier arrivals, [2] exit tickets, [3] sticky error word
-};
-
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_fused_kernel(BnFusedArgs a) {
-    __shared__ double red[256 * 16];
-    __shared__ double red2[16][16][2];
-    __shared__ int flag;
-    const int C = a.G * 8, nb = gridDim.x;
-    colsum_partial<MODE, true>(a.z, a.dy, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.relu, a.part, red);
-    bool ok = grid_barrier(a.sync + 0, (unsigned)nb, &flag);
-    for (int c0 = blockIdx.x * 16; c0 < C; c0 += nb * 16) {  // workgroup-uniform trip count: stage2_sum contains a barrier
-        const int c = c0 + (threadIdx.x & 15);
-        double sa, sb;
-        if (stage2_sum<true>(a.part, nb, C, c, sa, sb, red2)) {
-            if (MODE == 0) {
-                const double n = (double)a.M, m = sa / n;
-                double v = sb / n - m * m;
-                if (v < 0.0) v = 0.0;
-                st_x<true>(a.mean + c, (float)m); a.var[c] = (float)v; st_x<true>(a.invstd + c, (float)(1.0 / sqrt(v + (double)a.eps)));
-                if (a.running_mean) a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
-                if (a.running_var) a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
-            } else {
-                st_x<true>(a.dbeta + c, (float)sa); st_x<true>(a.dgamma + c, (float)sb);
-            }
-        }
-        __syncthreads();                                    // red2 is reused by the next channel slab
-    }
-    ok = grid_barrier(a.sync + 1, (unsigned)nb, &flag) && ok;
-    if (MODE == 0) bn_apply_body<true>(a.z, a.M, a.G, a.mean, a.invstd, a.gamma, a.beta, a.residual, a.relu, a.out);
-    else bn_backward_apply_body<true>(a.z, a.dy, a.M, a.G, (float)(1.0 / (double)a.M), a.mean, a.invstd, a.gamma, a.beta, a.dbeta, a.dgamma, a.relu, a.out);
-    if (threadIdx.x == 0) {
-        if (!ok) __hip_atomic_store(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // every workgroup takes its exit ticket AFTER it has seen barrier 2 complete, so nobody is spinning on the counters when the last one clears them
-        if (__hip_atomic_fetch_add(a.sync + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1) {
-            __hip_atomic_store(a.sync + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.sync + 2, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
 // 2x2/2 max-pool backward: the gradient goes to the first maximum of the window in scan order (ATen's max_pool2d picks `val > max`), plus an
@@ -1068,68 +988,6 @@ extern "C" int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin
 
 extern "C" size_t smirk_train_reduce_workspace_bytes(int C) { return (size_t)RED_BLOCKS * (size_t)C * 2 * sizeof(double); }
 
-// ---- one-launch BatchNorm (bn_fused_kernel): library-owned barrier counters, one 64-byte set per stream -----------------------------------------
-#define BN_SYNC_SLOTS 256
-#define BN_FUSED_MAX_BYTES (64ll << 20)
-#define BN_FUSED_BLOCKS 256
-static std::mutex g_bn_mu;
-static unsigned* g_bn_pool = nullptr;
-static bool g_bn_pool_failed = false;
-static std::unordered_map<hipStream_t, int> g_bn_slots;
-static int g_bn_fused_override = -1;
-static bool bn_fused_enabled() {
-    // default OFF: measured slower than three launches on this 8-XCD part (85 vs 47 us per forward call, train64 step 52.6 vs 45.6 ms, gpurun_out/r02ai) —
-    // a grid barrier costs ~15-20 us even with cache-bypassing accesses, more than the gap between dependent launches, and 256 co-resident workgroups
-    // stream at a fraction of what 2048 do; kept selectable and tested
-    static const int env = [] { const char* e = getenv("SMIRK_BN_FUSED"); return e ? atoi(e) : 0; }();
-    return (g_bn_fused_override >= 0 ? g_bn_fused_override : env) != 0;
-}
-// the stream's counter set, or nullptr when none can be had right now (first use while the stream is being captured into a graph: allocating would
-// invalidate the capture — the caller then takes the three-launch path, which computes the same thing)
-static unsigned* bn_sync_for(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_bn_mu);
-    if (g_bn_pool_failed) return nullptr;
-    if (!g_bn_pool) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
-        unsigned* p = nullptr;
-        if (hipMalloc((void**)&p, BN_SYNC_SLOTS * 64) != hipSuccess || hipMemset(p, 0, BN_SYNC_SLOTS * 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            (void)hipGetLastError();
-            g_bn_pool_failed = true;
-            return nullptr;
-        }
-        g_bn_pool = p;
-    }
-    auto it = g_bn_slots.find(st);
-    if (it == g_bn_slots.end()) {
-        if (g_bn_slots.size() >= BN_SYNC_SLOTS) return nullptr;
-        it = g_bn_slots.emplace(st, (int)g_bn_slots.size()).first;
-    }
-    return g_bn_pool + it->second * 16;
-}
-extern "C" int smirk_bn_set_fused(int on) {
-    const int prev = bn_fused_enabled() ? 1 : 0;
-    g_bn_fused_override = on;
-    return prev;
-}
-// number of streams whose one-launch BatchNorm ever timed out in a grid barrier (0 = never; synchronises the device)
-extern "C" int smirk_bn_fused_errors(void) {
-    std::lock_guard<std::mutex> lk(g_bn_mu);
-    if (!g_bn_pool) return 0;
-    static unsigned host[BN_SYNC_SLOTS * 16];
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, g_bn_pool, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return SMIRK_ERR_LAUNCH;
-    int n = 0;
-    for (int i = 0; i < BN_SYNC_SLOTS; ++i) n += host[i * 16 + 3] ? 1 : 0;
-    return n;
-}
-// grid of the one-launch form, or 0 when the tensor takes the three-launch path
-static unsigned bn_fused_grid(size_t M, int C) {
-    if (!bn_fused_enabled() || (long long)M * C * 4 > BN_FUSED_MAX_BYTES) return 0;
-    const int RPB = 256 / (C / 8);
-    const size_t rows = (M + RPB - 1) / RPB;
-    return (unsigned)(rows > BN_FUSED_BLOCKS ? BN_FUSED_BLOCKS : rows);
-}
-
 extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
                                               float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var,
                                               float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream) {
@@ -1137,17 +995,6 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    if (const unsigned fg = bn_fused_grid(M, C)) {
-        if (unsigned* sync = bn_sync_for(st)) {
-            BnFusedArgs a;
-            a.z = (const float*)z; a.dy = nullptr; a.M = M; a.G = G; a.relu = relu; a.gamma = gamma; a.beta = beta; a.residual = (const float*)residual;
-            a.eps = eps; a.momentum = momentum; a.mean = save_mean; a.var = save_var; a.invstd = save_invstd; a.running_mean = running_mean;
-            a.running_var = running_var; a.out = (float*)y; a.dgamma = nullptr; a.dbeta = nullptr; a.part = (double*)ws; a.sync = sync;
-            smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 4 : 3));
-            SMIRK_LAUNCH(bn_fused_kernel<0>, dim3(fg), dim3(256), 0, st, a);
-            return smirk_launch_status();
-        }
-    }
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
@@ -1168,17 +1015,6 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    if (const unsigned fg = bn_fused_grid(M, C)) {
-        if (unsigned* sync = bn_sync_for(st)) {
-            BnFusedArgs a;
-            a.z = (const float*)z; a.dy = (const float*)dy; a.M = M; a.G = G; a.relu = relu; a.gamma = gamma; a.beta = beta; a.residual = nullptr;
-            a.eps = 0.f; a.momentum = 0.f; a.mean = (float*)save_mean; a.var = nullptr; a.invstd = (float*)save_invstd; a.running_mean = nullptr;
-            a.running_var = nullptr; a.out = (float*)dz; a.dgamma = dgamma; a.dbeta = dbeta; a.part = (double*)ws; a.sync = sync;
-            smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 5);
-            SMIRK_LAUNCH(bn_fused_kernel<1>, dim3(fg), dim3(256), 0, st, a);
-            return smirk_launch_status();
-        }
-    }
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);

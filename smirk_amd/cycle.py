@@ -101,7 +101,10 @@ def graph_cycle_modules(generator, encoder, generator_input, encoder_input, grad
     The sample tensors fix the shapes: `generator_input` [B, 6, H, W] (no gradient needed, as in smirk_trainer.py:293), `encoder_input` [B, 3, H, W].
     Returns (generator_for_cycle, encoder_for_cycle): wrappers to call exactly like the modules (same shapes as the samples); the modules themselves are
     left untouched and keep launching kernel by kernel.
-    Note: capturing runs the modules `warmup` + 1 times, which advances BatchNorm running statistics like that many training steps."""
+    Note: capturing runs the modules `warmup` + 1 times, which advances BatchNorm running statistics like that many training steps.
+    Note: replays write running_mean / running_var / num_batches_tracked from captured kernels, so torch's `_version` counters do not move; the modules'
+    eval-mode weight caches (folded BatchNorm) are therefore dropped on every train() <-> eval() transition (SmirkGenerator.train,
+    MobileNetV3Features.train) — call `.eval()` AFTER the last replay, as `nn.Module` users do anyway."""
     if not (generator.training and encoder.training):
         raise ValueError("graph_cycle_modules captures the TRAIN-mode path: call .train() first")
     enc = _CycleEncoder(encoder, grad_keys)

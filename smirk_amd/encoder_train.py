@@ -8,8 +8,8 @@ the IMAGE gradient that the cycle loss sends back into the generator (config_tra
 
 One torch.autograd.Function per backbone.  Forward: bare stem / depthwise / pointwise convolutions, each followed by
 `smirk_bn_train_forward_split16`; global average pool + Linear; the ExpressionEncoder clamps (smirk_encoder.py:104-107).  Backward walks the tape:
-BatchNorm backward, pointwise data gradients on the forward implicit-GEMM kernel with the transposed weight, pointwise weight gradients on the exact
-fp32 MFMA kernel, depthwise / stem / head companions from csrc/train_encoder.hip.  Weight gradients are computed only for parameters that require
+BatchNorm backward, pointwise data gradients on the forward implicit-GEMM kernel with the transposed weight, pointwise weight gradients on the
+split-fp16 x3 weight-gradient kernels (`smirk_conv_wgrad_f32`, default mode 2; the exact-fp32 MFMA kernels are selectable with $SMIRK_WGRAD_F16=0), depthwise / stem / head companions from csrc/train_encoder.hip.  Weight gradients are computed only for parameters that require
 them, the image gradient only if the image requires it.
 """
 import torch
@@ -133,6 +133,9 @@ class BackboneTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.tape is None:
+            raise RuntimeError("BackboneTrainFunction.backward called a second time: the tape of raw convolution outputs is released after the first "
+                               "backward pass (retain_graph=True is not supported by the HIP training path; run the forward again)")
         backbone, head, tape = ctx.backbone, ctx.head, ctx.tape
         hw_, pooled, raw, n_exp, (B, hf, wf, Cf, N) = ctx.headrec
         ops = _EncOps(raw.device)

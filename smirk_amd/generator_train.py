@@ -79,11 +79,15 @@ class _Ops:
         mean, var, inv = (torch.empty(C, device=self.dev) for _ in range(3))
         y = torch.empty_like(z)
         P = L.ptr
+        track = bn.running_mean is not None and bn.running_var is not None
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        # nn.BatchNorm2d: momentum=None means a cumulative moving average, factor 1 / num_batches_tracked (after the increment above)
+        mom = float(bn.momentum) if bn.momentum is not None else (1.0 / max(int(bn.num_batches_tracked), 1) if track else 0.0)
         L.check(self.lib.smirk_bn_train_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
-                                                        float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1), P(bn.running_mean),
-                                                        P(bn.running_var), P(mean), P(var), P(inv), P(y), P(self.red_ws, torch.uint8),
-                                                        self.red_ws.numel(), self.st))
-        bn.num_batches_tracked += 1
+                                                        float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),
+                                                        P(bn.running_var if track else None, allow_none=True), P(mean), P(var), P(inv), P(y),
+                                                        P(self.red_ws, torch.uint8), self.red_ws.numel(), self.st))
         return y, mean, inv
 
     def bn_backward(self, z, dy, bn, mean, inv, relu):
@@ -195,37 +199,49 @@ class GeneratorTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if ctx.tape is None:
+            raise RuntimeError("GeneratorTrainFunction.backward called a second time: the tape of raw convolution outputs is released after the first "
+                               "backward pass (retain_graph=True is not supported by the HIP training path; run the forward again)")
         module, tape, (d1, wf, y) = ctx.module, ctx.tape, ctx.final
         B, Cx, H, W = ctx.shape
         f = module.features
         ops = _Ops(y.device)
         lib, st = ops.lib, ops.st
         grads = {}                                                        # id(parameter) -> gradient in the parameter's layout
+        need = lambda p: p.requires_grad                                  # a frozen generator (freeze_generator) pays for data gradients only
+        want_dx = bool(ctx.needs_input_grad[1])
         gy = L.as_f32c(gy)
         # ---- final 1x1 conv + sigmoid ------------------------------------------------------------------------------------------------------
         dd = torch.empty_like(d1)
         dl8 = torch.empty(B, H, W, 8, device=y.device)
         L.check(lib.smirk_conv1x1_sigmoid_backward_split16(L.ptr(gy), L.ptr(y), L.ptr(wf), L.ptr(dd), L.ptr(dl8), B, H, W, f, module.out_channels, st))
-        grads[id(module.conv.weight)] = ops.wgrad(dl8, d1, B, H, W, 8, f, 1)[:module.out_channels].reshape(module.out_channels, f, 1, 1)
-        grads[id(module.conv.bias)] = ops.colsum(dl8)[:module.out_channels].contiguous()
+        if need(module.conv.weight):
+            grads[id(module.conv.weight)] = ops.wgrad(dl8, d1, B, H, W, 8, f, 1)[:module.out_channels].reshape(module.out_channels, f, 1, 1)
+        if need(module.conv.bias):
+            grads[id(module.conv.bias)] = ops.colsum(dl8)[:module.out_channels].contiguous()
 
         def block_backward(rec, g):
             """g = dL/d(block output) -> (dL/d x0, dL/d x1 or None)"""
             _, (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2, wd1a, wd1b, wd2), (h, w, c) = rec
             dz2, dg2, db2 = ops.bn_backward(z2, g, n2, mu2, iv2, True)
             grads[id(n2.weight)], grads[id(n2.bias)] = dg2, db2
-            grads[id(c2.weight)] = _to_conv_weight_grad(ops.wgrad(dz2, y1, B, h, w, c, c, 3), c, c)
+            if need(c2.weight):
+                grads[id(c2.weight)] = _to_conv_weight_grad(ops.wgrad(dz2, y1, B, h, w, c, c, 3), c, c)
             dy1 = ops.conv(dz2, None, wd2, B, h, w, c)
             dz1, dg1, db1 = ops.bn_backward(z1, dy1, n1, mu1, iv1, True)
             grads[id(n1.weight)], grads[id(n1.bias)] = dg1, db1
             c0 = x0.shape[-1]
             if x1 is None:
-                grads[id(c1.weight)] = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0, cin_real=c1.weight.shape[1])
+                if need(c1.weight):
+                    grads[id(c1.weight)] = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0, cin_real=c1.weight.shape[1])
+                if rec is tape[0] and not want_dx:                        # the network input needs no gradient (cycle path: it is detached)
+                    return None, None
                 return ops.conv(dz1, None, wd1a, B, h, w, c0), None
             cc1 = x1.shape[-1]
-            gw0 = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0)
-            gw1 = _to_conv_weight_grad(ops.wgrad(dz1, x1, B, h, w, c, cc1, 3), c, cc1)
-            grads[id(c1.weight)] = torch.cat([gw0, gw1], 1)                # torch.cat((up, skip), 1): channels of source 0 first
+            if need(c1.weight):
+                gw0 = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0)
+                gw1 = _to_conv_weight_grad(ops.wgrad(dz1, x1, B, h, w, c, cc1, 3), c, cc1)
+                grads[id(c1.weight)] = torch.cat([gw0, gw1], 1)            # torch.cat((up, skip), 1): channels of source 0 first
             return ops.conv(dz1, None, wd1a, B, h, w, c0), ops.conv(dz1, None, wd1b, B, h, w, cc1)
 
         g = dd
@@ -245,22 +261,26 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 (up,), (xin_,), (h, w, cin, cout) = rec[1], rec[2], rec[3]
                 s2d = torch.empty(B, h, w, 4 * cout, device=y.device)
                 L.check(lib.smirk_space_to_depth2_split16(L.ptr(g), L.ptr(s2d), B, h, w, cout, st))
-                grads[id(up.bias)] = ops.colsum(g)
-                gw = ops.wgrad(xin_, s2d, B, h, w, cin, 4 * cout, 1)       # [Cin][(dy,dx,co)]
-                grads[id(up.weight)] = gw.reshape(cin, 2, 2, cout).permute(0, 3, 1, 2).contiguous()
+                if need(up.bias):
+                    grads[id(up.bias)] = ops.colsum(g)
+                if need(up.weight):
+                    gw = ops.wgrad(xin_, s2d, B, h, w, cin, 4 * cout, 1)   # [Cin][(dy,dx,co)]
+                    grads[id(up.weight)] = gw.reshape(cin, 2, 2, cout).permute(0, 3, 1, 2).contiguous()
                 wd = _split16(up.weight.detach().float().permute(0, 2, 3, 1).reshape(cin, 4 * cout).contiguous())
                 g = ops.conv(s2d, None, wd, B, h, w, cin, k=1)
             elif kind == "res":
                 _, (ca, na, cbv, nbv), (bin_, za, mua, iva, ya, zb, mub, ivb, wda, wdb), (h, w, c) = rec
                 dzb, dgb, dbb = ops.bn_backward(zb, g, nbv, mub, ivb, False)
                 grads[id(nbv.weight)], grads[id(nbv.bias)] = dgb, dbb
-                grads[id(cbv.weight)] = _to_conv_weight_grad(ops.wgrad(dzb, ya, B, h, w, c, c, 3, reflect=True), c, c)
+                if need(cbv.weight):
+                    grads[id(cbv.weight)] = _to_conv_weight_grad(ops.wgrad(dzb, ya, B, h, w, c, c, 3, reflect=True), c, c)
                 dpad = ops.conv(dzb, None, wdb, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 dya = torch.empty_like(ya)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), None, L.ptr(dya), B, h, w, c, st))
                 dza, dga, dba = ops.bn_backward(za, dya, na, mua, iva, True)
                 grads[id(na.weight)], grads[id(na.bias)] = dga, dba
-                grads[id(ca.weight)] = _to_conv_weight_grad(ops.wgrad(dza, bin_, B, h, w, c, c, 3, reflect=True), c, c)
+                if need(ca.weight):
+                    grads[id(ca.weight)] = _to_conv_weight_grad(ops.wgrad(dza, bin_, B, h, w, c, c, 3, reflect=True), c, c)
                 dpad = ops.conv(dza, None, wda, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 gin = torch.empty_like(bin_)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), L.ptr(g), L.ptr(gin), B, h, w, c, st))     # + the identity branch
@@ -272,7 +292,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 L.check(lib.smirk_maxpool2x2_backward_split16(L.ptr(t), L.ptr(g), L.ptr(skip_grad.get(level), allow_none=True), L.ptr(gx), B, h, w, c, st))
                 g = gx
             i -= 1
-        dx = split16_to_float(g)[..., :Cx].permute(0, 3, 1, 2).contiguous()
+        dx = split16_to_float(g)[..., :Cx].permute(0, 3, 1, 2).contiguous() if (want_dx and g is not None) else None
         ctx.tape = ctx.final = None
         out = [None, dx]
         for p in module.parameters():

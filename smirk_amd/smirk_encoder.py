@@ -102,6 +102,14 @@ class MobileNetV3Features(nn.Module):
         self._wcache = {}
         self._ws = L.Workspace()
 
+    def train(self, mode=True):
+        """see SmirkGenerator.train: train <-> eval transitions drop the folded-BatchNorm weight cache (graph replays update running statistics without
+        bumping torch's version counters)"""
+        if bool(mode) != self.training:
+            self._packed, self._packed_key = None, None
+            self._wcache = {}
+        return super().train(mode)
+
     def _key(self):
         return (PRECISION,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 

@@ -94,6 +94,14 @@ class SmirkGenerator(nn.Module):
         self._ws = L.Workspace()
         self.precision = os.environ.get("SMIRK_AMD_GENERATOR_PRECISION", "f16x3")
 
+    def train(self, mode=True):
+        """nn.Module.train / .eval.  The eval-mode weight image folds BatchNorm's RUNNING statistics and is cached on (data_ptr, _version) of every
+        parameter and buffer; HIP-graph replays of the train-mode path (smirk_amd.cycle.graph_cycle_modules) update the running statistics from captured
+        kernels without bumping torch's version counters, so every train <-> eval transition drops the cache and the next eval forward re-folds."""
+        if bool(mode) != self.training:
+            self._packed = self._packed_key = self._wstruct = self._wstruct_key = None
+        return super().train(mode)
+
     # ---- weight packing (device-side, cached until a parameter changes) ---------------------------------------------------
     def _key(self):
         return (self.precision,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))

@@ -125,3 +125,64 @@ def test_encoder_error_budget_against_float64(enc):
         assert e_hip <= 4.0 * e_cpu + 2e-6, (k, e_hip, e_cpu)
         assert e_hip < TOL[k] / 2, (k, e_hip)
     print("encoder max |error| vs float64 (HIP f16x3, torch-CPU fp32):", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})
+
+
+@pytest.mark.parametrize("stride,residual", [(1, True), (1, False), (2, False)])
+@pytest.mark.parametrize("hw", [(224, 224), (61, 75), (32, 48)])
+def test_encoder_head_fused_kernel_vs_float64(stride, residual, hw):
+    """csrc/encoder_head.hip: stem conv 3x3 s2 (TF-SAME) + BN + ReLU -> depthwise 3x3 (stride 1 | 2, TF-SAME) + BN + ReLU -> 1x1 16->16 + BN (+ stem
+    output) in one launch, against torch float64 on odd and even image sizes (ragged tiles, both padding parities)."""
+    import math
+    import torch.nn.functional as F
+    from smirk_amd import _lib as L
+    from smirk_amd.smirk_generator import _split16, split16_to_float
+    H, W = hw
+    B = 3
+    g = torch.Generator().manual_seed(H * 7 + stride)
+    img = torch.rand(B, 3, H, W, generator=g)
+    ws = torch.randn(16, 3, 3, 3, generator=g) * 0.4
+    wd = torch.randn(16, 1, 3, 3, generator=g) * 0.4
+    wp = torch.randn(16, 16, generator=g) * 0.3
+    aff = [(torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.2) for _ in range(3)]
+
+    def same_pad(x, s):
+        ih, iw = x.shape[-2:]
+        ph = max((math.ceil(ih / s) - 1) * s + 3 - ih, 0); pw = max((math.ceil(iw / s) - 1) * s + 3 - iw, 0)
+        return F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    wps = _split16(wp.cuda().contiguous())                                                   # the pointwise weight as the backbone stores it
+    wp64 = split16_to_float(wps.reshape(1, 1, 16, 16)).reshape(16, 16).cpu().double()
+    bc = lambda t: t.double()[None, :, None, None]
+    s = F.relu(F.conv2d(same_pad(img.double(), 2), ws.double(), stride=2) * bc(aff[0][0]) + bc(aff[0][1]))
+    d = F.conv2d(same_pad(s, 2), wd.double(), stride=2, groups=16) if stride == 2 else F.conv2d(s, wd.double(), padding=1, groups=16)
+    d = F.relu(d * bc(aff[1][0]) + bc(aff[1][1]))
+    ref = F.conv2d(d, wp64[:, :, None, None]) * bc(aff[2][0]) + bc(aff[2][1])
+    if residual:
+        ref = ref + s
+    Ho, Wo = ref.shape[-2:]
+    out = torch.empty(B, Ho, Wo, 16, device="cuda")
+    P = L.ptr
+    dev = lambda t: t.float().contiguous().cuda()
+    t = [dev(img), dev(ws.permute(0, 2, 3, 1).reshape(16, 27)), dev(aff[0][0]), dev(aff[0][1]), dev(wd.reshape(16, 9).t()), dev(aff[1][0]), dev(aff[1][1]),
+         wps, dev(aff[2][0]), dev(aff[2][1])]
+    L.check(L.lib().smirk_encoder_head_fused_split16(*[P(x) for x in t], int(residual), P(out), B, H, W, stride, L.stream_ptr()))
+    got = split16_to_float(out).permute(0, 3, 1, 2).cpu().double()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (200, 184), (72, 104)])
+def test_fused_encoder_head_matches_three_launch_sequence(enc, hw):
+    """the whole backbone with the fused stem + first block (default) against the stem / depthwise / pointwise launches it replaces"""
+    from smirk_amd.smirk_encoder import features_f32
+    m, _ = enc
+    img = A.synth_images(3, seed=19)[:, :, :hw[0], :hw[1]].contiguous().cuda()
+    for name in ("pose_encoder", "shape_encoder"):
+        bb = getattr(m, name).encoder
+        os.environ["SMIRK_DISABLE_ENCODER_HEAD_FUSED"] = "1"
+        try:
+            ref = features_f32(bb, bb(img)).cpu()
+        finally:
+            del os.environ["SMIRK_DISABLE_ENCODER_HEAD_FUSED"]
+        got = features_f32(bb, bb(img)).cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name

@@ -41,19 +41,12 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("relu,res", [(True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("shape", [(3, 6, 10, 32), (2, 4, 4, 512), (1, 16, 16, 64), (2, 40, 40, 72)])
-def test_batchnorm_train_forward_backward(shape, relu, res, fused):
-    """train-mode BatchNorm forward (+ running statistics) and backward against float64 autograd, as ONE cooperative launch (fused = 1: grid barriers between the
-    partial sums, the finalisation and the element-wise pass) and as three launches (fused = 0); a grid barrier must never have timed out"""
+def test_batchnorm_train_forward_backward(shape, relu, res):
+    """train-mode BatchNorm forward (+ running statistics) and backward against float64 autograd"""
     T, ops = _ops()
-    ops.lib.smirk_bn_set_fused(fused)
-    try:
-        _batchnorm_case(T, ops, shape, relu, res)
-    finally:
-        ops.lib.smirk_bn_set_fused(-1)
-    assert ops.lib.smirk_bn_fused_errors() == 0
+    _batchnorm_case(T, ops, shape, relu, res)
 
 
 def _batchnorm_case(T, ops, shape, relu, res):
@@ -387,29 +380,17 @@ def test_weight_packing_kernel_is_bitwise_the_torch_packing(cout, cin, k, off, s
     assert dgr.shape == want_d.shape and torch.equal(dgr.view(torch.int32), want_d.view(torch.int32))
 
 
-def test_batchnorm_one_launch_equals_three_launches_closely_and_is_deterministic():
-    """the two forms differ only in how many partial sums the fp64 statistics are split into (256 vs 512 workgroups): outputs agree to fp32 round-off of the
-    statistics, and each form reproduces itself bit for bit"""
+def test_batchnorm_train_is_deterministic():
+    """fixed-order fp64 partial sums: the BatchNorm forward / backward reproduce themselves bit for bit"""
     T, ops = _ops()
     g = _gen(77)
     bn = torch.nn.BatchNorm2d(120).cuda().train()
     zs, _ = _act(torch.randn(4, 28, 28, 120, generator=g) * 1.5 + 0.3)
     dys, _ = _act(torch.randn(4, 28, 28, 120, generator=g))
-    outs = {}
-    for fused in (1, 0):
-        ops.lib.smirk_bn_set_fused(fused)
-        try:
-            runs = []
-            for _ in range(3):
-                y, mean, inv = ops.bn_forward(zs, bn, True)
-                dz, dg, db = ops.bn_backward(zs, dys, bn, mean, inv, True)
-                runs.append([t.clone() for t in (y, mean, inv, dz, dg, db)])
-            for r in runs[1:]:
-                assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
-            outs[fused] = runs[0]
-        finally:
-            ops.lib.smirk_bn_set_fused(-1)
-    for a, b in zip(outs[1], outs[0]):
-        fa, fb = (_val(a), _val(b)) if a.dim() == 4 else (a.cpu().double(), b.cpu().double())
-        assert _rel(fa, fb) < 1e-6
-    assert ops.lib.smirk_bn_fused_errors() == 0
+    runs = []
+    for _ in range(3):
+        y, mean, inv = ops.bn_forward(zs, bn, True)
+        dz, dg, db = ops.bn_backward(zs, dys, bn, mean, inv, True)
+        runs.append([t.clone() for t in (y, mean, inv, dz, dg, db)])
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
