@@ -16,7 +16,7 @@
 //      phase D  pointwise 16 -> 16 + BN (+ residual S), lane = (pixel, 8-channel half), weights broadcast from LDS    -> split16 NHWC store
 // HBM traffic: the image patch ((37/32)^2 = 1.34x of the tile's pixels at stride 1, 1.20x at stride 2) + the output; S and D never leave the CU.
 // Arithmetic: fp32 FMA throughout (the intermediate tensors are NOT rounded to the 22-bit split16 storage in between, unlike the unfused sequence).
-// Bound: VALU issue (~950 FMA per lane and tile) at ~0.4 ms per 1024 frames against ~0.3 ms of HBM time; 2 (stride 1: 54 KB of LDS) / 4 (stride 2) workgroups per CU hide the LDS latencies.
+// Bound: VALU issue (~950 FMA per lane and tile) at ~0.4 ms per 1024 frames against ~0.3 ms of HBM time; 3-4 workgroups per CU (39 / 34 KB of LDS: the depthwise output re-uses the image patch's LDS) hide the memory and LDS latencies.
 #include <stdio.h>
 
 #include "common.h"
@@ -42,14 +42,16 @@ struct EncHeadArgs {
 };
 
 template <int S>
-__global__ __launch_bounds__(256, 2) void encoder_head_fused_kernel(EncHeadArgs a) {
+__global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs a) {
     constexpr int TO = (S == 1) ? 16 : 8;               // output tile
     constexpr int TS = (TO - 1) * S + 3;                // stem-image halo tile (18 | 17)
     constexpr int TI = (TS - 1) * 2 + 3;                // image patch (37 | 35)
     constexpr int TIP = TI + 1;                         // LDS row stride of the patch
-    __shared__ float Is[3 * TI * TIP];                  // image patch [c][y][x]
+    constexpr int ISZ = 3 * TI * TIP, DSZ = TO * TO * 16;
+    __shared__ __attribute__((aligned(16))) float IDs[ISZ > DSZ ? ISZ : DSZ];   // image patch [c][y][x]; dead after phase B, then the depthwise output [p][16]
     __shared__ __attribute__((aligned(16))) float Ss[TS * TS * 16];   // stem output [y][x][16]
-    __shared__ __attribute__((aligned(16))) float Ds[TO * TO * 16];   // depthwise output [p][16]
+    float* Is = IDs;
+    float* Ds = IDs;
     __shared__ __attribute__((aligned(16))) float Wp[16 * 16];        // pointwise weights [cin][cout] (transposed: a lane reads 8 couts of one cin)
     const int tid = threadIdx.x, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -62,13 +64,27 @@ __global__ __launch_bounds__(256, 2) void encoder_head_fused_kernel(EncHeadArgs 
 
     // ---- phase A: image patch, pointwise weights ------------------------------------------------------------------------------------------------
     {
+        // all of a lane's patch elements are requested before the first one is stored: one memory round trip per tile instead of one per element
+        // (first version: a rolled load -> store loop, 17 dependent global round trips per tile, 2.2 ms per 1024 frames)
         const float* ib = a.img + (size_t)b * 3 * a.H * a.W;
-        for (int i = tid; i < 3 * TI * TI; i += 256) {
+        constexpr int NIT = (3 * TI * TI + 255) / 256;
+        float v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
             const int c = i / (TI * TI), r = i - c * TI * TI, y = r / TI, x = r - y * TI;
             const int iy = iy0 + y, ix = ix0 + x;
-            float v = 0.f;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = ib[((size_t)c * a.H + iy) * a.W + ix];
-            Is[(c * TI + y) * TIP + x] = v;
+            const bool ok = i < 3 * TI * TI && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            // branch-free: always load from a clamped in-image address, select afterwards (predicated loads came out as 17 exec-masked branches)
+            const int cc = min(c, 2), yc = min(max(iy, 0), a.H - 1), xc = min(max(ix, 0), a.W - 1);
+            const float t = ib[(cc * a.H + yc) * a.W + xc];
+            v[it] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int c = i / (TI * TI), r = i - c * TI * TI, y = r / TI, x = r - y * TI;
+            if (i < 3 * TI * TI) Is[(c * TI + y) * TIP + x] = v[it];
         }
         {   // thread = (cout, cin): split16 row of cout, group cin / 8, element cin % 8
             const int co = tid >> 4, ci = tid & 15;
