@@ -285,6 +285,13 @@ int smirk_transfer_pixels(const float* img, const int64_t* points1, const int64_
  * scale / shift.  The expanded tensors never leave the CU's LDS.  All channel counts must be multiples of 8. */
 size_t smirk_mbconv_lds_bytes(int Cin, int mid, int Cout, int stride);
 /* 1 if the fused kernel serves this block shape (Cin <= 48, Cout <= 96, LDS <= 64 KiB); otherwise use the per-layer kernels */
+/* InvertedResidual block with WHOLE images per workgroup (stride 1, H * W <= 224 — the 14 x 14 / 7 x 7 stages, Cin a multiple of 16 up to 112, Cout <= 128:
+ * timm InvertedResidual; reference call site src/smirk_encoder.py:18-21,52-55,80-83): same arguments and arithmetic as
+ * smirk_mbconv_fused_split16, no halo recompute; x stays in LDS, the expanded / depthwise tensors never exist in memory.  _supported: 1 when served. */
+int smirk_mbconv_image_supported(int H, int W, int Cin, int mid, int Cout, int stride);
+int smirk_mbconv_image_split16(const void* x, const void* wexp, const float* s1, const float* b1, const float* wdw, const float* s2, const float* b2,
+                               const void* wproj, const float* s3, const float* b3, int residual, void* out, int B, int H, int W, int Cin, int mid,
+                               int Cout, void* stream);
 /* Stem + first DepthwiseSeparable block of a MobileNetV3-minimal backbone in ONE launch (timm `conv_stem` + `bn1` + `blocks[0][0]`; reference call site
  * src/smirk_encoder.py:18-21,52-55,80-83 `self.encoder(img)[-1]`): img[B][3][H][W] NCHW fp32 -> 3x3 s2 conv 3->16 + BN + ReLU -> 3x3 depthwise (stride 1 | 2,
  * TF-SAME) + BN + ReLU -> 1x1 16->16 + BN (+ the stem output when residual) -> out split16 NHWC [B][Ho][Wo][16].  stem_w [16][27] fp32 (k = (ky,kx,c)),

@@ -92,6 +92,8 @@ _SIGS = {
     "smirk_project_landmarks_backward": (_i, [_p, _p, _p, _i, _i, _p, _p, _p]),
     "smirk_encoder_head_supported": (_i, [_i] * 7),
     "smirk_encoder_head_fused_split16": (_i, [_p] * 10 + [_i, _p] + [_i] * 4 + [_p]),
+    "smirk_mbconv_image_supported": (_i, [_i] * 6),
+    "smirk_mbconv_image_split16": (_i, [_p] * 10 + [_i, _p] + [_i] * 6 + [_p]),
     "smirk_mbconv_lds_bytes": (_sz, [_i, _i, _i, _i]),
     "smirk_mbconv_supported": (_i, [_i, _i, _i, _i]),
     "smirk_mbconv_fused_split16": (_i, [_p] * 10 + [_i, _p] + [_i] * 7 + [_p]),

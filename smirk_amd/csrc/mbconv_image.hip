@@ -1,0 +1,358 @@
+// mbconv_image.hip — image-resident fused MobileNetV3 InvertedResidual block for the <= 14 x 14 stages of the timm "minimal" backbones (gfx950):
+//
+//      x --1x1 expand + BN + ReLU--> E --3x3 depthwise (stride 1, pad 1) + BN + ReLU--> D --1x1 project + BN (+x)--> out
+//
+// (reference call site smirk_encoder.py:18-21,52-55,80-83 `self.encoder(img)[-1]`.)  mbconv.hip fuses the blocks with Cin <= 48 on
+// 8 x 8 tiles; the 14 x 14 / 7 x 7 blocks with 80-112 input channels ran as three launches (pointwise / depthwise / pointwise) that write and re-read
+// the 3-6x wider expanded tensors: at 1024 frames 17 ms of ~2 TB/s kernels for 2 % of the path's flops (round-2 verdict, item 3d).  Here ONE workgroup
+// owns WHOLE images — one 14 x 14 image or four 7 x 7 images = 196 pixels = seven 32-row MFMA blocks, one per wave — so there is no halo to recompute:
+//   * x (196 px x Cin, split16 as stored) is loaded into LDS once and stays there (A operand of the expand GEMM, residual of the epilogue);
+//   * the expanded channels are walked in chunks of 32:
+//       beta   P1(c)   E_c = relu(bn1(X . Wexp_c))   3 x v_mfma_f32_32x32x16_f16 per 16-k step (split-fp16 x3), Wexp_c fragments prefetched into registers,
+//                      scattered as fp32 into a zero-bordered (H+2) x (W+2) grid in LDS (the depthwise conv pads E, not x);
+//       alpha  DW(c)   every lane computes depthwise + BN + ReLU for ITS pixel row and ITS 8 channels of each 16-k step — exactly the MFMA A-operand
+//                      fragment (row = lane % 32, k = 8 (lane / 32) ..) of the project GEMM — straight into registers: D never exists in memory;
+//       beta   P3(c)   P += D_c . Wproj_c, the wave's four 32-column accumulator tiles (Cout <= 128) stay in registers across the chunks; Wproj_c is
+//                      staged through LDS once per workgroup (register-staged copy one chunk ahead, 144-byte rows: conflict-free fragment reads);
+//     two barriers per chunk (alpha | beta: the grid is rewritten by P1(c+1) only after every wave has read it for DW(c));
+//   * epilogue: bn3 (+ x from LDS), per-wave transpose through LDS, whole 8-channel split16 groups to HBM.
+// HBM traffic per block: x in + out (0.16 GB at 1024 frames for 112 -> 672 -> 112 instead of 2.3 GB).  LDS: 91 KB (x) + 32 KB (E grid, XOR-swizzled
+// 16-byte slots) + 2 x 16 KB (Wproj chunks) + tables = 156 KB in the largest case: one 512-thread workgroup per CU.
+// Bound: latency / issue (1 workgroup per CU, phases separated by barriers); the point is the 14x smaller memory footprint, not MFMA occupancy.
+// Arithmetic identical in kind to mbconv.hip (f16x3 products, fp32 accumulation, fp32 depthwise, E kept in fp32).
+#include <stdio.h>
+
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct MBIArgs {
+    const char* x;          // split16 NHWC, Cin*4 bytes per pixel
+    const char* wexp;       // [mid][Cin] split16 rows
+    const float *s1, *b1;   // [mid]
+    const float* wdw;       // [9][mid]
+    const float *s2, *b2;   // [mid]
+    const char* wproj;      // [Cout][mid] split16 rows
+    const float *s3, *b3;   // [Cout]
+    char* out;              // split16 NHWC [B][H][W][Cout]
+    int B, H, W, Cin, mid, Cout, residual, ipw, rows, gsz, nb;   // ipw images per workgroup, rows = ipw*H*W (<= 224), gsz = ipw*(H+2)*(W+2), nb = ceil(rows/32)
+    int off_es, off_wp, off_wc, off_gmap;                        // byte offsets into the dynamic LDS block
+};
+
+__device__ __forceinline__ void mbi_barrier() {              // LDS-only barrier: global prefetches stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// fp32 offset of (grid position gi, channel c) inside the E grid: rows of 32 floats, the eight 16-byte slots of a row XOR-swizzled with (gi >> 1) & 7 so
+// that the 16 lanes of a ds_read_b128 group (16 neighbouring pixels, same channel quad) hit 16 distinct slots
+__device__ __forceinline__ int mbi_es(int gi, int c) { return gi * 32 + ((((c >> 2) ^ (gi >> 1)) & 7) << 2) + (c & 3); }
+
+// KS = Cin / 16 (16-k MFMA steps of the expand GEMM), NT = 32-column tiles of the project GEMM (Cout <= 32 NT)
+template <int KS, int NT>
+__global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char mbi_smem[];
+    const int strideX = a.Cin * 4 + 16;                 // odd multiple of 16 B
+    char* Xs = mbi_smem;
+    float* Es = (float*)(mbi_smem + a.off_es);
+    char* Wp = mbi_smem + a.off_wp;                     // 2 x [Cout][144 B]
+    float* Wc = (float*)(mbi_smem + a.off_wc);          // 2 x [11][32]: 9 depthwise taps, s2, b2 of a chunk
+    short* gmap = (short*)(mbi_smem + a.off_gmap);      // [nb * 32]: grid position of input / output pixel row r (-1: no such row)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, hb = lane >> 5;
+    const int b0 = blockIdx.x * a.ipw;
+    const int nimg = min(a.ipw, a.B - b0), HW = a.H * a.W, vrows = nimg * HW;   // valid rows (the last workgroup may hold fewer images)
+    const int nchunks = (a.mid + 31) / 32;
+    const size_t xrow = (size_t)a.Cin * 4;
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool active = wave < a.nb;                    // one 32-row block per wave
+    const int wpbuf = a.Cout * 144;
+
+    // ---- prefetch helpers ----------------------------------------------------------------------------------------------------------------------------
+    half8 we[KS][2];                                    // expand-weight fragments of the chunk P1 computes next (column = 32 c + fr)
+    float s1v = 0.f, b1v = 0.f;
+    auto load_we = [&](int c) {
+        // channels beyond mid (ragged last chunk): the fragments of a clamped row are loaded unconditionally (no branches in the loop) and the chunk's
+        // BN constants are zeroed instead, so E = relu(finite * 0 + 0) = 0 there
+        const int ch = 32 * c + fr;
+        const bool v = ch < a.mid;
+        const int chc = min(ch, a.mid - 1);
+        const char* wrow = a.wexp + (size_t)chc * xrow;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int g = 2 * s + hb;
+            we[s][0] = *(const half8*)(wrow + g * 32);
+            we[s][1] = *(const half8*)(wrow + g * 32 + 16);
+        }
+        const float t1 = a.s1[chc], t2 = a.b1[chc];
+        s1v = v ? t1 : 0.f;
+        b1v = v ? t2 : 0.f;
+    };
+    // Wproj chunk c: Cout rows x 128 B (4 groups of [8 hi][8 lo]) = Cout x 8 sixteen-byte vectors, <= 2 per thread; Wc chunk: 11 x 32 floats
+    f32x4 wpv[2];
+    float wcv = 0.f;
+    auto fetch_stage = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 512 * u, row = idx >> 3, piece = idx & 7, kg = 4 * c + (piece >> 1);
+            const bool ok = row < a.Cout && kg * 8 < a.mid;
+            const int rc = min(row, a.Cout - 1), kc = min(kg, a.mid / 8 - 1);
+            const f32x4 t = *(const f32x4*)(a.wproj + ((size_t)rc * a.mid + kc * 8) * 4 + (piece & 1) * 16);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            wpv[u] = ok ? t : z;
+        }
+        {   // 11 x 32 depthwise / BN constants: wdw is [9][mid], s2 and b2 follow the same indexing through a pointer select
+            const int k = min(tid >> 5, 10), ch = 32 * c + (tid & 31), chc = min(ch, a.mid - 1);
+            const float* src = k < 9 ? a.wdw + (size_t)k * a.mid : (k == 9 ? a.s2 : a.b2);
+            const float t = src[chc];
+            wcv = ch < a.mid ? t : 0.f;
+        }
+    };
+    auto store_stage = [&](int c) {
+        char* dst = Wp + (c & 1) * wpbuf;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 512 * u, row = idx >> 3, piece = idx & 7;
+            if (row < a.Cout) *(f32x4*)(dst + row * 144 + piece * 16) = wpv[u];
+        }
+        if (tid < 352) Wc[(c & 1) * 352 + tid] = wcv;
+    };
+
+    // ---- phase 0: x -> LDS, zero grid, row -> grid map ----------------------------------------------------------------------------------------------
+    {
+        const int P = a.Cin / 4;                         // 16-byte vectors per row
+        const char* xb = a.x + (size_t)b0 * HW * xrow;
+        for (int idx = tid; idx < a.rows * P; idx += 512) {
+            const int row = idx / P, pc = idx - row * P;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < vrows) v = *(const f32x4*)(xb + (size_t)row * xrow + pc * 16);
+            *(f32x4*)(Xs + row * strideX + pc * 16) = v;
+        }
+        for (int idx = tid; idx < (a.gsz + 1) * 8; idx += 512) ((f32x4*)Es)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = tid; r < a.nb * 32; r += 512) {
+            int g = a.gsz;                              // rows that do not exist scatter into a dump row behind the grid
+            if (r < vrows) {
+                const int im = r / HW, rem = r - im * HW, y = rem / a.W, xx = rem - y * a.W;
+                g = (im * (a.H + 2) + y + 1) * (a.W + 2) + xx + 1;
+            }
+            gmap[r] = (short)g;
+        }
+    }
+    mbi_barrier();
+
+    f32x16 pacc[NT][2];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[q][h][r] = 0.f;
+    const int myrow = min(wave * 32 + fr, a.rows - 1);  // clamped: rows beyond the last one duplicate it and are never stored
+    const int mygi0 = active ? (int)gmap[min(wave * 32 + fr, a.nb * 32 - 1)] : a.gsz;
+    const int mygi = mygi0 < a.gsz ? mygi0 : -1;
+
+    // P1: expand chunk (fragments in `we`, BN constants in s1v / b1v) -> E grid
+    auto expand = [&]() {
+        if (!active) return;
+        f32x16 e0, e1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
+        const char* arow = Xs + myrow * strideX;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int g = 2 * s + hb;
+            const half8 ah = *(const half8*)(arow + g * 32), al = *(const half8*)(arow + g * 32 + 16);
+            e0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, we[s][0], e0, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, we[s][1], e1, 0, 0, 0);
+            e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, we[s][0], e1, 0, 0, 0);
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);      // at most two k-steps of A fragments in flight: the register file is full (128 accumulators)
+        }
+        int rbase = wave * 32 + 4 * hb;                 // row of accumulator register r: rbase + (r & 3) + 8 (r >> 2)
+        asm volatile("" : "+v"(rbase));                 // re-read the 16 grid positions from LDS every chunk instead of keeping them in registers
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gi = gmap[rbase + (r & 3) + 8 * (r >> 2)];
+            Es[mbi_es(gi, fr)] = fmaxf((e0[r] + e1[r] * (1.0f / 2048.0f)) * s1v + b1v, 0.f);
+        }
+    };
+
+
+    // chunk loop; iteration c = -1 only stages chunk 0 and expands it (one copy of every phase's code: the kernel is register-bound)
+    for (int c = -1; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) fetch_stage(c + 1);                   // global -> registers, lands under the depthwise arithmetic
+        // ---- alpha: depthwise 3x3 + BN + ReLU of this lane's pixel row, 8 channels per 16-k step -> MFMA A fragments ----------------------------------
+        half8 dh[2] = {hz, hz}, dl[2] = {hz, hz};
+        if (c >= 0 && active && mygi >= 0) {
+            const float* wc = Wc + (c & 1) * 352;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c8 = 8 * (2 * s + hb);
+                int gc = mygi;
+                asm volatile("" : "+v"(gc));            // re-derive the 18 grid addresses per 16-k step and per chunk: kept in registers (LICM across the chunk
+                                                        // loop, CSE across the two k-steps) they cost ~60 VGPRs beside the 128 accumulators -> scratch spills
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int gi = gc + (ky - 1) * (a.W + 2) + (kx - 1);
+                        const f32x4 v0 = *(const f32x4*)(Es + mbi_es(gi, c8)), v1 = *(const f32x4*)(Es + mbi_es(gi, c8 + 4));
+                        const f32x4 w0 = *(const f32x4*)(wc + (ky * 3 + kx) * 32 + c8), w1 = *(const f32x4*)(wc + (ky * 3 + kx) * 32 + c8 + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { acc[q] = fmaf(v0[q], w0[q], acc[q]); acc[4 + q] = fmaf(v1[q], w1[q], acc[4 + q]); }
+                        if (kx == 2) __builtin_amdgcn_sched_barrier(0);   // at most one tap row (12 ds_read_b128 = 48 registers) in flight beside the 128 accumulators
+                    }
+                const f32x4 sa = *(const f32x4*)(wc + 9 * 32 + c8), sb = *(const f32x4*)(wc + 9 * 32 + c8 + 4);
+                const f32x4 ba = *(const f32x4*)(wc + 10 * 32 + c8), bb = *(const f32x4*)(wc + 10 * 32 + c8 + 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = fmaxf(acc[q] * (q < 4 ? sa[q & 3] : sb[q & 3]) + (q < 4 ? ba[q & 3] : bb[q & 3]), 0.f);
+                    _Float16 h, l;
+                    smirk_split1(v, h, l);
+                    dh[s][q] = h; dl[s][q] = l;
+                }
+            }
+        }
+        if (more) store_stage(c + 1);                   // the other Wp / Wc buffer: last read in chunk c-1, read next after two barriers
+        mbi_barrier();                                  // every wave has read the grid for DW(c): P1(c+1) may overwrite it
+        // ---- beta: project chunk c, then expand chunk c+1 ----------------------------------------------------------------------------------------------
+        if (more) load_we(c + 1);                       // lands under the project MFMAs
+        if (c >= 0 && active) {
+            const char* wp = Wp + (c & 1) * wpbuf;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int co = min(q * 32 + fr, a.Cout - 1);      // columns beyond Cout duplicate the last row and are never stored
+                const char* brow = wp + co * 144;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int g = 2 * s + hb;
+                    const half8 bhh = *(const half8*)(brow + g * 32), bll = *(const half8*)(brow + g * 32 + 16);
+                    pacc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[s], bhh, pacc[q][0], 0, 0, 0);
+                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[s], bll, pacc[q][1], 0, 0, 0);
+                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl[s], bhh, pacc[q][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one tile's B fragments at a time (hoisting all 4 NT sets costs 64 registers)
+            }
+        }
+        if (more) expand();
+        mbi_barrier();
+    }
+
+    // ---- epilogue: bn3 (+ x), per-wave 32 x 32 transposes through the (now free) grid region, split16 stores ---------------------------------------------
+    if (active) {
+        float* tb = Es + wave * (32 * 36);              // 32 rows x 36 floats per wave: 7 x 4608 B <= the 32 KB grid
+        char* ob = a.out + (size_t)b0 * HW * a.Cout * 4;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            if (q * 32 < a.Cout) {
+                const int co = q * 32 + fr;
+                const float s3 = co < a.Cout ? a.s3[co] : 0.f, b3 = co < a.Cout ? a.b3[co] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[mfma32_row(r, lane) * 36 + fr] = (pacc[q][0][r] + pacc[q][1][r] * (1.0f / 2048.0f)) * s3 + b3;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {        // 32 rows x 4 groups = 128 items over 64 lanes
+                    const int item = it * 64 + lane, row = item >> 2, g8 = q * 4 + (item & 3);
+                    const int r = wave * 32 + row;
+                    if (r < vrows && g8 * 8 < a.Cout) {
+                        float v[8];
+                        *(f32x4*)v = *(const f32x4*)(tb + row * 36 + (item & 3) * 8);
+                        *(f32x4*)(v + 4) = *(const f32x4*)(tb + row * 36 + (item & 3) * 8 + 4);
+                        if (a.residual) {
+                            const char* xr = Xs + r * strideX + g8 * 32;
+                            const half8 hi = *(const half8*)xr, lo = *(const half8*)(xr + 16);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] += (float)hi[k] + (float)lo[k] * (1.0f / 2048.0f);
+                        }
+                        half8 hi, lo;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            _Float16 h, l;
+                            smirk_split1(v[k], h, l);
+                            hi[k] = h; lo[k] = l;
+                        }
+                        char* o = ob + ((size_t)r * a.Cout + g8 * 8) * 4;
+                        *(half8*)o = hi;
+                        *(half8*)(o + 16) = lo;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    }
+}
+
+struct MbiPlan { int ipw, rows, gsz, nb, off_es, off_wp, off_wc, off_gmap; size_t lds; };
+static bool mbi_plan(int H, int W, int Cin, int mid, int Cout, MbiPlan& p) {
+    if (H <= 0 || W <= 0 || H * W > 224 || Cin % 16 || mid % 8 || Cout % 8 || Cin < 16 || Cin > 112 || Cout > 128 || mid <= 0 || Cout <= 0) return false;
+    p.ipw = 224 / (H * W);
+    if (p.ipw > 8) p.ipw = 8;
+    p.rows = p.ipw * H * W;
+    p.gsz = p.ipw * (H + 2) * (W + 2);
+    p.nb = (p.rows + 31) / 32;
+    if (p.nb > 7 || p.gsz * 128 < p.nb * 32 * 36 * 4) return false;   // one row block per wave (8 waves, one spare); the epilogue's transposes fit the grid
+    size_t o = (size_t)p.rows * (Cin * 4 + 16);
+    o = (o + 15) / 16 * 16; p.off_es = (int)o; o += (size_t)p.gsz * 128;
+    p.off_wp = (int)o; o += (size_t)2 * Cout * 144;
+    p.off_wc = (int)o; o += 2 * 352 * 4;
+    p.off_gmap = (int)o; o += (size_t)p.nb * 32 * 2;
+    p.lds = (o + 15) / 16 * 16;
+    return p.lds <= 160 * 1024;
+}
+
+// (Cin / 16, ceil(Cout / 32)) pairs that are instantiated: 80 -> 80, 80 -> 112, 96 -> 96, 112 -> 112 are the blocks of the two backbones
+static bool mbi_has_variant(int ks, int nt) {
+    return (ks == 5 && (nt == 2 || nt == 3 || nt == 4)) || (ks == 6 && (nt == 3 || nt == 4)) || (ks == 7 && (nt == 3 || nt == 4)) ||
+           (ks == 4 && (nt == 2 || nt == 3));
+}
+
+/* 1 if smirk_mbconv_image_split16 serves this InvertedResidual block (stride 1, whole images per workgroup) */
+extern "C" int smirk_mbconv_image_supported(int H, int W, int Cin, int mid, int Cout, int stride) {
+    MbiPlan p;
+    return stride == 1 && mbi_plan(H, W, Cin, mid, Cout, p) && mbi_has_variant(Cin / 16, (Cout + 31) / 32) ? 1 : 0;
+}
+
+template <int KS, int NT>
+static int mbi_launch(const MBIArgs& a, unsigned grid, size_t lds, hipStream_t st, double flop, double bytes) {
+    static bool attr_done[64] = {};                      // hipFuncSetAttribute is per-device state
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)mbconv_image_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SMIRK_ERR_LAUNCH;
+        attr_done[dev] = true;
+    }
+    if (g_smirk_prof_on) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "mbconv_image_kernel<%d,%d>", KS, NT);
+        smirk_prof_next(nm, flop, bytes);
+    }
+    SMIRK_LAUNCH((mbconv_image_kernel<KS, NT>), dim3(grid), dim3(512), lds, st, a);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_mbconv_image_split16(const void* x, const void* wexp, const float* s1, const float* b1, const float* wdw, const float* s2,
+                                          const float* b2, const void* wproj, const float* s3, const float* b3, int residual, void* out, int B,
+                                          int H, int W, int Cin, int mid, int Cout, void* stream) {
+    if (!x || !wexp || !s1 || !b1 || !wdw || !s2 || !b2 || !wproj || !s3 || !b3 || !out || B <= 0) return SMIRK_ERR_BAD_ARG;
+    if (residual && Cin != Cout) return SMIRK_ERR_BAD_ARG;
+    MbiPlan p;
+    if (!mbi_plan(H, W, Cin, mid, Cout, p)) return SMIRK_ERR_UNSUPPORTED;
+    MBIArgs a;
+    a.x = (const char*)x; a.wexp = (const char*)wexp; a.s1 = s1; a.b1 = b1; a.wdw = wdw; a.s2 = s2; a.b2 = b2; a.wproj = (const char*)wproj;
+    a.s3 = s3; a.b3 = b3; a.out = (char*)out; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.mid = mid; a.Cout = Cout; a.residual = residual;
+    a.ipw = p.ipw; a.rows = p.rows; a.gsz = p.gsz; a.nb = p.nb; a.off_es = p.off_es; a.off_wp = p.off_wp; a.off_wc = p.off_wc; a.off_gmap = p.off_gmap;
+    const unsigned grid = (unsigned)((B + p.ipw - 1) / p.ipw);
+    hipStream_t st = (hipStream_t)stream;
+    const double px = (double)B * H * W;
+    const double flop = 2.0 * px * ((double)Cin * mid + 9.0 * mid + (double)mid * Cout);
+    const double bytes = 4.0 * px * (Cin * (residual ? 2 : 1) + Cout);
+    const int ks = Cin / 16, nt = (Cout + 31) / 32;
+#define MBI_CASE(K, N) if (ks == K && nt == N) return mbi_launch<K, N>(a, grid, p.lds, st, flop, bytes)
+    MBI_CASE(5, 3); MBI_CASE(5, 4); MBI_CASE(6, 3); MBI_CASE(7, 4);          // mbi_has_variant lists the same pairs
+    MBI_CASE(4, 2); MBI_CASE(4, 3); MBI_CASE(5, 2); MBI_CASE(6, 4); MBI_CASE(7, 3);
+#undef MBI_CASE
+    return SMIRK_ERR_UNSUPPORTED;
+}

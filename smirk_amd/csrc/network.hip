@@ -240,6 +240,7 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
     const BackbonePlan p = plan_backbone(w, B, H, W, ws);
     if (ws_bytes < p.total) return SMIRK_ERR_WORKSPACE;
     const bool split = w->precision == SMIRK_PRECISION_F16X3;
+    const bool no_image = getenv("SMIRK_DISABLE_MBCONV_IMAGE") != nullptr;                                                       // A/B switch (tests)
     const bool no_fuse = getenv("SMIRK_DISABLE_MBCONV_FUSED") != nullptr, fuse_ds = getenv("SMIRK_MBCONV_FUSE_DS") != nullptr;   // A/B switches (tests)
     int h = (H + 1) / 2, wd = (W + 1) / 2;
     void* x = p.rot.slot[0];
@@ -281,6 +282,11 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
             TRY(smirk_mbconv_fused_split16(x, b.kind == 1 ? b.pw.w : nullptr, b.kind == 1 ? b.pw.scale : nullptr, b.kind == 1 ? b.pw.shift : nullptr,
                                            (const float*)b.dw.w, b.dw.scale, b.dw.shift, proj.w, proj.scale, proj.shift, b.skip ? 1 : 0, o, B, h, wd,
                                            b.cin, b.mid, b.cout, b.stride, stream));
+            x = o;
+        } else if (split && !no_fuse && !no_image && b.kind == 1 && smirk_mbconv_image_supported(h, wd, b.cin, b.mid, b.cout, b.stride)) {
+            void* o = p.rot.pick(x, nullptr);                       // <= 14 x 14, 80-112 channels: whole images per workgroup (mbconv_image.hip)
+            TRY(smirk_mbconv_image_split16(x, b.pw.w, b.pw.scale, b.pw.shift, (const float*)b.dw.w, b.dw.scale, b.dw.shift, b.pwl.w, b.pwl.scale, b.pwl.shift,
+                                           b.skip ? 1 : 0, o, B, h, wd, b.cin, b.mid, b.cout, stream));
             x = o;
         } else if (b.kind == 0) {                                   // DepthwiseSeparable: dw + BN + ReLU -> pw + BN (+ x)
             void* t = p.rot.pick(x, nullptr);

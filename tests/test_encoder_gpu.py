@@ -186,3 +186,62 @@ def test_fused_encoder_head_matches_three_launch_sequence(enc, hw):
         got = features_f32(bb, bb(img)).cpu()
         assert got.shape == ref.shape
         assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
+
+
+@pytest.mark.parametrize("cfg", [dict(B=3, H=14, W=14, cin=112, mid=672, cout=112, res=True), dict(B=5, H=7, W=7, cin=96, mid=576, cout=96, res=True),
+                                 dict(B=2, H=14, W=14, cin=80, mid=200, cout=80, res=True), dict(B=4, H=14, W=14, cin=80, mid=184, cout=80, res=True),
+                                 dict(B=3, H=14, W=14, cin=80, mid=480, cout=112, res=False), dict(B=9, H=5, W=7, cin=64, mid=136, cout=48, res=False),
+                                 dict(B=2, H=13, W=12, cin=112, mid=96, cout=88, res=False)])
+def test_mbconv_image_kernel_vs_float64(cfg):
+    """csrc/mbconv_image.hip: 1x1 expand + BN + ReLU -> 3x3 depthwise (pad 1) + BN + ReLU -> 1x1 project + BN (+ x), whole images per workgroup, against
+    torch float64 on the operands' exact split16 values: the backbones' 14x14 / 7x7 shapes (ragged last chunk: mid 200 / 184; ragged last workgroup:
+    B = 5 with four 7x7 images per workgroup) and odd geometries."""
+    import torch.nn.functional as F
+    from smirk_amd import _lib as L
+    from smirk_amd.smirk_generator import _split16, split16_to_float
+    B, H, W, cin, mid, cout, res = (cfg[k] for k in ("B", "H", "W", "cin", "mid", "cout", "res"))
+    lib = L.lib()
+    assert lib.smirk_mbconv_image_supported(H, W, cin, mid, cout, 1) == 1
+    g = torch.Generator().manual_seed(H * 31 + mid)
+    x = torch.randn(B, H, W, cin, generator=g)
+    we = torch.randn(mid, cin, generator=g) * (1.5 / cin ** 0.5)
+    wd = torch.randn(mid, 3, 3, generator=g) * 0.4
+    wp = torch.randn(cout, mid, generator=g) * (1.5 / mid ** 0.5)
+    aff = [(torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g) * 0.2) for n in (mid, mid, cout)]
+    xs = _split16(x.reshape(-1, cin).cuda()).reshape(B, H, W, cin)
+    wes, wps = _split16(we.cuda().contiguous()), _split16(wp.cuda().contiguous())
+    x64 = split16_to_float(xs).double().cpu().permute(0, 3, 1, 2)
+    we64 = split16_to_float(wes.reshape(1, 1, mid, cin)).reshape(mid, cin).double().cpu()
+    wp64 = split16_to_float(wps.reshape(1, 1, cout, mid)).reshape(cout, mid).double().cpu()
+    bc = lambda t: t.double()[None, :, None, None]
+    e = F.relu(F.conv2d(x64, we64[:, :, None, None]) * bc(aff[0][0]) + bc(aff[0][1]))
+    d = F.relu(F.conv2d(e, wd.double()[:, None], padding=1, groups=mid) * bc(aff[1][0]) + bc(aff[1][1]))
+    ref = F.conv2d(d, wp64[:, :, None, None]) * bc(aff[2][0]) + bc(aff[2][1])
+    if res:
+        ref = ref + x64
+    out = torch.empty(B, H, W, cout, device="cuda")
+    P = L.ptr
+    dev = lambda t: t.float().contiguous().cuda()
+    t = [xs, wes, dev(aff[0][0]), dev(aff[0][1]), dev(wd.reshape(mid, 9).t()), dev(aff[1][0]), dev(aff[1][1]), wps, dev(aff[2][0]), dev(aff[2][1])]
+    L.check(lib.smirk_mbconv_image_split16(*[P(v) for v in t], int(res), P(out), B, H, W, cin, mid, cout, L.stream_ptr()))
+    got = split16_to_float(out).permute(0, 3, 1, 2).cpu().double()
+    # D is rounded to the 22-bit split16 fragment format before the project GEMM (as in mbconv.hip and the unfused sequence): 2^-22 relative per term
+    assert (got - ref).abs().max().item() < 4e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("hw,B", [((224, 224), 3), ((224, 224), 5), ((200, 184), 2), ((72, 104), 9)])
+def test_image_resident_mbconv_blocks_match_unfused_sequence(enc, hw, B):
+    """the whole backbone with the image-resident blocks (default) against the pointwise / depthwise / pointwise launches they replace"""
+    from smirk_amd.smirk_encoder import features_f32
+    m, _ = enc
+    img = A.synth_images(B, seed=29)[:, :, :hw[0], :hw[1]].contiguous().cuda()
+    for name in ("pose_encoder", "shape_encoder"):
+        bb = getattr(m, name).encoder
+        os.environ["SMIRK_DISABLE_MBCONV_IMAGE"] = "1"
+        try:
+            ref = features_f32(bb, bb(img)).cpu()
+        finally:
+            del os.environ["SMIRK_DISABLE_MBCONV_IMAGE"]
+        got = features_f32(bb, bb(img)).cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
