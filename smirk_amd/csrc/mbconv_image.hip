@@ -128,9 +128,9 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
             if (row < vrows) v = *(const f32x4*)(xb + (size_t)row * xrow + pc * 16);
             *(f32x4*)(Xs + row * strideX + pc * 16) = v;
         }
-        for (int idx = tid; idx < (a.gsz + 1) * 8; idx += 512) ((f32x4*)Es)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int idx = tid; idx < a.gsz * 8; idx += 512) ((f32x4*)Es)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int r = tid; r < a.nb * 32; r += 512) {
-            int g = a.gsz;                              // rows that do not exist scatter into a dump row behind the grid
+            int g = -1;                                 // rows that do not exist
             if (r < vrows) {
                 const int im = r / HW, rem = r - im * HW, y = rem / a.W, xx = rem - y * a.W;
                 g = (im * (a.H + 2) + y + 1) * (a.W + 2) + xx + 1;
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pacc[q][h][r] = 0.f;
     const int myrow = min(wave * 32 + fr, a.rows - 1);  // clamped: rows beyond the last one duplicate it and are never stored
-    const int mygi0 = active ? (int)gmap[min(wave * 32 + fr, a.nb * 32 - 1)] : a.gsz;
-    const int mygi = mygi0 < a.gsz ? mygi0 : -1;
+    const int mygi = active ? (int)gmap[min(wave * 32 + fr, a.nb * 32 - 1)] : -1;
 
     // P1: expand chunk (fragments in `we`, BN constants in s1v / b1v) -> E grid
     auto expand = [&]() {
@@ -171,8 +170,10 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
         asm volatile("" : "+v"(rbase));                 // re-read the 16 grid positions from LDS every chunk instead of keeping them in registers
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int gi = gmap[rbase + (r & 3) + 8 * (r >> 2)];
-            Es[mbi_es(gi, fr)] = fmaxf((e0[r] + e1[r] * (1.0f / 2048.0f)) * s1v + b1v, 0.f);
+            // rows that do not exist (beyond the workgroup's last image) carry gmap = -1: they store 0 into border cell 0, which is 0 anyway — no branch
+            const int gm = gmap[rbase + (r & 3) + 8 * (r >> 2)];
+            const float v = fmaxf((e0[r] + e1[r] * (1.0f / 2048.0f)) * s1v + b1v, 0.f);
+            Es[mbi_es(max(gm, 0), fr)] = gm >= 0 ? v : 0.f;
         }
     };
 
