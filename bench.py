@@ -83,6 +83,9 @@ def parse_args(argv=None):
     ap.add_argument("--traffic", choices=("measure", "file", "off"), default=None,
                     help="roofline.traffic: run two rocprofv3 --pmc passes of this script (default at 1 GPU), read profiles/pmc_traffic.json, or skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--flame-basis", choices=("random", "smooth"), default="random",
+                    help="synthetic FLAME blendshape basis: 'random' = SURVEY.md 8(d) (i.i.d. directions: ~21 x 22-pixel triangle boxes); 'smooth' = low-frequency "
+                         "fields like a real shape model (~4-pixel triangles) - only the rasteriser's share of the step changes")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo stub of the path: tests/test_distributed_cpu.py
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)       # the run that rocprofv3 wraps (no JSON line, no baseline)
@@ -110,7 +113,7 @@ def build_modules(sandbox, device, want=("enc", "flame", "rend", "gen")):
     O(1) through all 30+ layers (nn.Conv2d's default init shrinks them by ~2.4x per layer); every output is checked finite after warm-up."""
     import torch
     from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, synth
-    synth.write_sandbox(sandbox)
+    synth.write_sandbox(sandbox, basis=os.environ.get("SMIRK_BENCH_FLAME_BASIS", "random"))
     cwd = os.getcwd()
     os.chdir(sandbox)
     try:
@@ -158,14 +161,22 @@ def output_stats(out):
 # ------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle = a port of the reference path; checker code, timed beside the GPU on a bounded sample)
 # ------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sandbox, workload, n_faces):
+def cpu_baseline(sandbox, workload, n_faces, threads=None):
+    """threads=None: the 32-thread measurement (more threads than that only thrash on the bounded sample) PLUS, under "all_cores", the same sample
+    with torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 asks; threads=N: that thread count only."""
+    if threads is None:
+        base = cpu_baseline(sandbox, workload, n_faces, threads=min(os.cpu_count(), 32))
+        if os.cpu_count() > base["cores"]:
+            allc = cpu_baseline(sandbox, workload, n_faces, threads=os.cpu_count())
+            base["all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "stage_seconds", "sample")}
+        return base
     import numpy as np
     import torch
     from oracle import generator_ref as G, mobilenet_ref as M
     from oracle.flame_ref import FlameRef
     from oracle.render_ref import RendererRef
     from smirk_amd import synth
-    nthr = min(os.cpu_count(), 32)          # more threads than this only thrash on a small sample
+    nthr = int(threads)
     torch.set_num_threads(nthr)
     os.environ["OMP_NUM_THREADS"] = str(nthr)
     fr = FlameRef(sandbox)
@@ -610,6 +621,7 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
 
 def main():
     args = parse_args()
+    os.environ["SMIRK_BENCH_FLAME_BASIS"] = args.flame_basis     # read by build_modules (also in the ranks / rocprofv3 children this process launches)
     if args.micro_batch is None:
         args.micro_batch = MICRO_BATCH
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -699,13 +711,13 @@ def main():
                 mode = "file"
         if table is None and mode == "file":
             try:
-                j = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+                j = json.load(open(os.path.join(REPO, "profiles", f"pmc_traffic_{args.workload}.json")))
                 if j.get("kernel_sources_sha") == kernel_sources_sha() and j.get("workload", "full") == args.workload:
-                    table, src = j["kernels"], src + "; profiles/pmc_traffic.json (same kernel sources, sha " + j["kernel_sources_sha"] + ")"
+                    table, src = j["kernels"], src + f"; profiles/pmc_traffic_{args.workload}.json (same kernel sources, sha " + j["kernel_sources_sha"] + ")"
                 else:
-                    src += "; profiles/pmc_traffic.json was measured on different kernel sources / workload -> traffic withheld (null)"
+                    src += f"; profiles/pmc_traffic_{args.workload}.json was measured on different kernel sources / workload -> traffic withheld (null)"
             except Exception:               # noqa: BLE001
-                src += "; no profiles/pmc_traffic.json"
+                src += f"; no profiles/pmc_traffic_{args.workload}.json"
         roof = roofline_from_records(recs, args.workload, table, src, dt / args.steps / max(1, len(getattr(wl, "slices", [0]))))
         if roof is not None and hasattr(wl, "instrumented_pipeline"):
             # the same kernel inside the overlapped schedule of the timed region (rocprofv3 --kernel-trace --stats of this command averages THIS state)

@@ -385,6 +385,13 @@ int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* 
 /* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
 int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* Eval-mode BatchNorm with a backward pass — the frozen, .eval() generator that smirk_trainer.py:108-113 back-propagates THROUGH (emotion loss):
+ * forward y = [relu]((z - running_mean) / sqrt(running_var + eps) * gamma + beta [+ residual]) and writes invstd[C] plus a zero vector zeros[C] for the
+ * backward; backward dz = gamma * invstd * dy * [relu mask recomputed from z] (no batch statistics: running estimates are constants). */
+int smirk_bn_eval_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  const void* residual, int relu, float eps, float* save_invstd, float* zeros, void* y, void* stream);
+int smirk_bn_eval_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* invstd, const float* zeros, int relu, void* dz, void* stream);
 /* sums[c] = sum over the M rows of x[.][c]  (bias gradients) */
 int smirk_colsum_split16(const void* x, size_t M, int C, float* sums, void* ws, size_t ws_bytes, void* stream);
 /* nn.MaxPool2d(2, 2) backward: dx[b,2y+i,2x+j,c] = dy[b,y,x,c] at the first maximum of the window (ATen scan order), 0 elsewhere, + add (nullable:

@@ -73,19 +73,20 @@ def _block(x, sd, mod, nm):
     return x
 
 
-def forward(sd, x, res_blocks=5, taps=None, _calib=None):
-    """x [B,6,224,224] fp32 -> [B,3,224,224]; optional `taps` dict collects intermediates for layer-wise parity."""
+def forward(sd, x, res_blocks=5, taps=None, _calib=None, grad=False):
+    """x [B,6,224,224] fp32 -> [B,3,224,224]; optional `taps` dict collects intermediates for layer-wise parity.
+    grad=True keeps the autograd graph (eval-mode BatchNorm inside a differentiated graph, smirk_trainer.py:108-113: dL/dx of the frozen generator)."""
     global _CALIB
     t = taps if taps is not None else {}
     _CALIB = _calib
     try:
-        return _forward(sd, x, res_blocks, t)
+        return _forward(sd, x, res_blocks, t, grad)
     finally:
         _CALIB = None
 
 
-def _forward(sd, x, res_blocks, t):
-    with torch.no_grad():
+def _forward(sd, x, res_blocks, t, grad=False):
+    with torch.set_grad_enabled(grad):
         e1 = _block(x, sd, "encoder1", "enc1"); t["enc1"] = e1
         e2 = _block(F.max_pool2d(e1, 2, 2), sd, "encoder2", "enc2"); t["enc2"] = e2
         e3 = _block(F.max_pool2d(e2, 2, 2), sd, "encoder3", "enc3"); t["enc3"] = e3

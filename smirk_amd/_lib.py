@@ -134,6 +134,8 @@ _SIGS = {
     "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
     "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
+    "smirk_bn_eval_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _p, _p, _i, C.c_float, _p, _p, _p, _p]),
+    "smirk_bn_eval_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _p, _i, _p, _p]),
     "smirk_colsum_split16": (_i, [_p, _sz, _i, _p, _p, _sz, _p]),
     "smirk_maxpool2x2_backward_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_reflect_pad1_backward_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -1024,6 +1024,39 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     return smirk_launch_status();
 }
 
+// ---- eval-mode BatchNorm of the differentiable generator (smirk_trainer.py:108-113: the frozen generator in .eval() inside a graph that is
+//      back-propagated to its input): y = [relu]((z - running_mean) * rsqrt(running_var + eps) * gamma + beta [+ residual]); the backward is the same
+//      element-wise kernel as in train mode with the two batch sums set to zero (dz = gamma * invstd * dy * relu mask).  No statistics, no reduction.
+__global__ __launch_bounds__(256) void bn_invstd_kernel(const float* __restrict__ var, float eps, int C, float* __restrict__ invstd, float* __restrict__ zeros) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) { invstd[c] = 1.0f / sqrtf(var[c] + eps); zeros[c] = 0.f; }
+}
+
+extern "C" int smirk_bn_eval_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const float* running_mean,
+                                             const float* running_var, const void* residual, int relu, float eps, float* save_invstd, float* zeros,
+                                             void* y, void* stream) {
+    if (!z || !gamma || !beta || !running_mean || !running_var || !save_invstd || !zeros || !y || M == 0 || C <= 0 || C % 8 || C / 8 > 256)
+        return SMIRK_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 8, RPB = 256 / G;
+    SMIRK_LAUNCH(bn_invstd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, running_var, eps, C, save_invstd, zeros);
+    smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
+    SMIRK_LAUNCH(bn_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, M, G, running_mean, (const float*)save_invstd, gamma, beta,
+                 (const float*)residual, relu, (float*)y);
+    return smirk_launch_status();
+}
+
+extern "C" int smirk_bn_eval_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta,
+                                              const float* running_mean, const float* invstd, const float* zeros, int relu, void* dz, void* stream) {
+    if (!z || !dy || !gamma || !beta || !running_mean || !invstd || !zeros || !dz || M == 0 || C <= 0 || C % 8 || C / 8 > 256) return SMIRK_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 8, RPB = 256 / G;
+    smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
+    SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, 0.0f, running_mean, invstd,
+                 gamma, beta, zeros, zeros, relu, (float*)dz);
+    return smirk_launch_status();
+}
+
 extern "C" int smirk_colsum_split16(const void* x, size_t M, int C, float* sums, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !sums || !ws || M == 0 || C <= 0 || C % 8 || C / 8 > 256) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;

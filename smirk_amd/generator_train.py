@@ -39,8 +39,9 @@ def _pack_dgrad(w, cout_pad=None):
 class _Ops:
     """thin stateful wrapper over the C entries: one reduction workspace, the launch stream, and conv descriptors"""
 
-    def __init__(self, device):
+    def __init__(self, device, eval_bn=False):
         self.lib, self.st, self.dev = L.lib(), L.stream_ptr(), device
+        self.eval_bn = bool(eval_bn)                     # BatchNorm from the running statistics (module in .eval() inside an autograd graph)
         self.red_ws = torch.empty(self.lib.smirk_train_reduce_workspace_bytes(1024), dtype=torch.uint8, device=device)
         self.wg_ws = None
 
@@ -79,6 +80,12 @@ class _Ops:
         mean, var, inv = (torch.empty(C, device=self.dev) for _ in range(3))
         y = torch.empty_like(z)
         P = L.ptr
+        if self.eval_bn:                                 # `mean` carries the zero vector the backward needs, `inv` = rsqrt(running_var + eps)
+            if bn.running_mean is None or bn.running_var is None:
+                raise L.SmirkHipError("eval-mode BatchNorm needs running statistics (track_running_stats=True)")
+            L.check(self.lib.smirk_bn_eval_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(bn.running_mean), P(bn.running_var),
+                                                           P(residual, allow_none=True), int(relu), float(bn.eps), P(inv), P(mean), P(y), self.st))
+            return y, mean, inv
         track = bn.running_mean is not None and bn.running_var is not None
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
@@ -95,6 +102,10 @@ class _Ops:
         M = z.numel() // C
         dz, dg, db = torch.empty_like(z), torch.empty(C, device=self.dev), torch.empty(C, device=self.dev)
         P = L.ptr
+        if self.eval_bn:                                 # dz = gamma * invstd * dy * relu-mask; the affine parameters' gradients are not needed (frozen)
+            L.check(self.lib.smirk_bn_eval_backward_split16(P(z), P(dy), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(bn.running_mean), P(inv),
+                                                            P(mean), int(relu), P(dz), self.st))
+            return dz, None, None
         L.check(self.lib.smirk_bn_train_backward_split16(P(z), P(dy), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(mean), P(inv), int(relu), P(dz),
                                                          P(dg), P(db), P(self.red_ws, torch.uint8), self.red_ws.numel(), self.st))
         return dz, dg, db
@@ -134,8 +145,9 @@ class GeneratorTrainFunction(torch.autograd.Function):
             raise L.SmirkHipError("SmirkGenerator: expected [B, in_channels, H, W] with H, W multiples of 16")
         if module.features % 8 or module.in_channels > 8:
             raise L.SmirkHipError("training runs in the split-fp16 mode: init_features % 8 == 0 and in_channels <= 8")
-        ops = _Ops(x.device)
+        ops = _Ops(x.device, eval_bn=not module.training)
         lib, st, f = ops.lib, ops.st, module.features
+        ctx.eval_bn = not module.training
         tape = []                                                         # records consumed in reverse by backward()
         xin = torch.empty(B, H, W, 8, device=x.device)
         L.check(lib.smirk_pack_generator_input_split16(L.ptr(x), Cx, None, 0, L.ptr(xin), B, H, W, st))
@@ -205,10 +217,16 @@ class GeneratorTrainFunction(torch.autograd.Function):
         module, tape, (d1, wf, y) = ctx.module, ctx.tape, ctx.final
         B, Cx, H, W = ctx.shape
         f = module.features
-        ops = _Ops(y.device)
+        ops = _Ops(y.device, eval_bn=ctx.eval_bn)
         lib, st = ops.lib, ops.st
         grads = {}                                                        # id(parameter) -> gradient in the parameter's layout
-        need = lambda p: p.requires_grad                                  # a frozen generator (freeze_generator) pays for data gradients only
+        # which parameters wanted a gradient WHEN THE FORWARD RAN (smirk_trainer.py:108-113 flips requires_grad off for the eval-mode forward and back on
+        # before backward): a frozen generator pays for data gradients only; in eval mode BatchNorm's affine gradients are not computed at all
+        wanted = {id(p) for p, n in zip(module.parameters(), ctx.needs_input_grad[2:]) if n}
+        if ctx.eval_bn and any(id(bn_p) in wanted for m_ in module.modules() if isinstance(m_, torch.nn.BatchNorm2d) for bn_p in m_.parameters()):
+            raise L.SmirkHipError("eval-mode SmirkGenerator inside autograd: parameter gradients are not implemented (freeze the generator as "
+                                  "smirk_trainer.py:108-113 does, or call .train())")
+        need = lambda p: id(p) in wanted
         want_dx = bool(ctx.needs_input_grad[1])
         gy = L.as_f32c(gy)
         # ---- final 1x1 conv + sigmoid ------------------------------------------------------------------------------------------------------
@@ -224,12 +242,14 @@ class GeneratorTrainFunction(torch.autograd.Function):
             """g = dL/d(block output) -> (dL/d x0, dL/d x1 or None)"""
             _, (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2, wd1a, wd1b, wd2), (h, w, c) = rec
             dz2, dg2, db2 = ops.bn_backward(z2, g, n2, mu2, iv2, True)
-            grads[id(n2.weight)], grads[id(n2.bias)] = dg2, db2
+            if dg2 is not None:
+                grads[id(n2.weight)], grads[id(n2.bias)] = dg2, db2
             if need(c2.weight):
                 grads[id(c2.weight)] = _to_conv_weight_grad(ops.wgrad(dz2, y1, B, h, w, c, c, 3), c, c)
             dy1 = ops.conv(dz2, None, wd2, B, h, w, c)
             dz1, dg1, db1 = ops.bn_backward(z1, dy1, n1, mu1, iv1, True)
-            grads[id(n1.weight)], grads[id(n1.bias)] = dg1, db1
+            if dg1 is not None:
+                grads[id(n1.weight)], grads[id(n1.bias)] = dg1, db1
             c0 = x0.shape[-1]
             if x1 is None:
                 if need(c1.weight):
@@ -271,14 +291,16 @@ class GeneratorTrainFunction(torch.autograd.Function):
             elif kind == "res":
                 _, (ca, na, cbv, nbv), (bin_, za, mua, iva, ya, zb, mub, ivb, wda, wdb), (h, w, c) = rec
                 dzb, dgb, dbb = ops.bn_backward(zb, g, nbv, mub, ivb, False)
-                grads[id(nbv.weight)], grads[id(nbv.bias)] = dgb, dbb
+                if dgb is not None:
+                    grads[id(nbv.weight)], grads[id(nbv.bias)] = dgb, dbb
                 if need(cbv.weight):
                     grads[id(cbv.weight)] = _to_conv_weight_grad(ops.wgrad(dzb, ya, B, h, w, c, c, 3, reflect=True), c, c)
                 dpad = ops.conv(dzb, None, wdb, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 dya = torch.empty_like(ya)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), None, L.ptr(dya), B, h, w, c, st))
                 dza, dga, dba = ops.bn_backward(za, dya, na, mua, iva, True)
-                grads[id(na.weight)], grads[id(na.bias)] = dga, dba
+                if dga is not None:
+                    grads[id(na.weight)], grads[id(na.bias)] = dga, dba
                 if need(ca.weight):
                     grads[id(ca.weight)] = _to_conv_weight_grad(ops.wgrad(dza, bin_, B, h, w, c, c, 3, reflect=True), c, c)
                 dpad = ops.conv(dza, None, wda, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))

@@ -180,6 +180,13 @@ class SmirkGenerator(nn.Module):
             x = a if b is None else torch.cat([a, b], 1)
             return GeneratorTrainFunction.apply(self, x, *self.parameters())
         srcs = [a] + ([] if b is None else [b])
+        if taps is None and self.precision == "f16x3" and torch.is_grad_enabled() and any(t.requires_grad for t in srcs):
+            # eval mode with an INPUT that requires grad — smirk_trainer.py:108-113 freezes the generator, calls .eval() and back-propagates the emotion
+            # loss through it into rendered_img: the same autograd.Function as train mode with BatchNorm taken from the running statistics.  (Forward-only
+            # callers whose parameters merely have requires_grad=True, like demo.py without no_grad, stay on the whole-network C entry below.)
+            from .generator_train import GeneratorTrainFunction
+            x = a if b is None else torch.cat([a, b], 1)
+            return GeneratorTrainFunction.apply(self, x, *self.parameters())
         a = L.as_f32c(a.detach())
         b = None if b is None else L.as_f32c(b.detach())
         B, Ca, H, W = a.shape

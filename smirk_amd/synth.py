@@ -22,18 +22,38 @@ def load_bundle(path=BUNDLE):
     return {k: z[k] for k in z.files}
 
 
-def synth_flame_model(bundle, seed=2020):
+def synth_flame_model(bundle, seed=2020, basis="random"):
     """Seeded synthetic stand-in for FLAME2020/generic_model.pkl.
 
     Keys / shapes are those FLAME.__init__ reads (FLAME.py:54-78): plain ndarrays so no
     chumpy is needed to unpickle.
+
+    basis="random" (the SURVEY.md §8(d) definition, used by every parity test): i.i.d. Gaussian blendshape directions — neighbouring vertices move
+    independently, so deformed triangles are stretched to ~21 x 22-pixel boxes at 224 x 224.
+    basis="smooth": every direction is a low-frequency vector field over the template (a random axis times a sinusoid of <= 2 cycles across the head)
+    with the same per-direction RMS — neighbouring vertices move together like a real statistical shape model, triangles keep their ~4-pixel size.
+    Only the rasteriser's work depends on this (bench.py --flame-basis smooth measures its share on realistic triangles).
     """
     rng = np.random.default_rng(seed)
     vt = bundle["obj_verts"].astype(np.float64)
     vt = vt - vt.mean(0, keepdims=True)
     decay = 0.985 ** np.arange(400)
-    shapedirs = rng.standard_normal((V, 3, 400)) * 5e-3 * decay[None, None, :]
-    posedirs = rng.standard_normal((V, 3, 36)) * 1e-3
+    if basis == "smooth":
+        ext = np.abs(vt).max()
+        def fields(n, amp):
+            axis = rng.standard_normal((n, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+            freq = rng.standard_normal((n, 3)); freq *= (rng.uniform(0.3, 2.0, (n, 1)) / np.linalg.norm(freq, axis=1, keepdims=True))
+            phase = rng.uniform(0, 2 * np.pi, n)
+            wave = np.sin(2 * np.pi * (vt / (2 * ext)) @ freq.T + phase[None, :])          # [V, n]
+            wave /= np.sqrt((wave ** 2).mean(0, keepdims=True))                            # unit RMS per direction
+            return wave[:, None, :] * axis.T[None, :, :] * np.sqrt(3.0) * amp               # [V, 3, n], per-component RMS ~ amp
+        shapedirs = fields(400, 5e-3 * decay[None, None, :])
+        posedirs = fields(36, 1e-3)
+    elif basis == "random":
+        shapedirs = rng.standard_normal((V, 3, 400)) * 5e-3 * decay[None, None, :]
+        posedirs = rng.standard_normal((V, 3, 36)) * 1e-3
+    else:
+        raise ValueError("basis must be 'random' or 'smooth'")
     jr = np.abs(rng.standard_normal((5, V)))
     jr /= jr.sum(1, keepdims=True)
     w = np.abs(rng.standard_normal((V, 5)))
@@ -54,8 +74,8 @@ def write_obj(path, verts, uvs, faces, tfaces):
             fh.write("f %d/%d %d/%d %d/%d\n" % (a[0] + 1, b[0] + 1, a[1] + 1, b[1] + 1, a[2] + 1, b[2] + 1))
 
 
-def write_sandbox(root, bundle=None, seed=2020):
-    """Create ``root/assets/...`` with every file FLAME() and Renderer() open. Returns root."""
+def write_sandbox(root, bundle=None, seed=2020, basis="random"):
+    """Create ``root/assets/...`` with every file FLAME() and Renderer() open. Returns root.  basis: see synth_flame_model."""
     import torch
     bundle = bundle if bundle is not None else load_bundle()
     a = os.path.join(root, "assets")
@@ -65,7 +85,7 @@ def write_sandbox(root, bundle=None, seed=2020):
     pkl = os.path.join(a, "FLAME2020", "generic_model.pkl")
     if not os.path.exists(pkl):
         with open(pkl, "wb") as fh:
-            pickle.dump(synth_flame_model(bundle, seed), fh, protocol=2)
+            pickle.dump(synth_flame_model(bundle, seed, basis), fh, protocol=2)
     np.save(os.path.join(a, "l_eyelid.npy"), bundle["l_eyelid"])
     np.save(os.path.join(a, "r_eyelid.npy"), bundle["r_eyelid"])
     emb = dict(

@@ -114,3 +114,50 @@ def test_train_mode_under_no_grad_and_eval_roundtrip():
         y2 = m(x)
     sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     assert (y2.cpu() - G.forward(sd2, x.cpu())).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("B,HW", [(2, 64), (1, 96)])
+def test_eval_mode_generator_is_differentiable_to_its_input(B, HW):
+    """smirk_trainer.py:108-113 (emotion loss): parameters frozen, `.eval()`, forward INSIDE the autograd graph, `requires_grad_(True)` again, `.train()`,
+    then backward — the loss must reach `rendered_img` through the frozen, eval-mode generator (BatchNorm from the running statistics) and leave no
+    parameter gradients.  Forward against the plain eval forward; dL/dx against float64 autograd through the oracle's eval-mode restatement."""
+    sd = G.synth_state_dict()
+    m = _module(sd)
+    g = torch.Generator().manual_seed(HW)
+    x = torch.rand(B, 6, HW, HW, generator=g)
+    wgt = torch.randn(B, 3, HW, HW, generator=g)
+    # --- the reference's call pattern -------------------------------------------------------------------------------------------------
+    xg = x.cuda().requires_grad_(True)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    m.eval()
+    y = m(xg)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    m.train()
+    assert y.requires_grad
+    with torch.no_grad():
+        m.eval()
+        y_plain = m(x.cuda())
+        m.train()
+    assert (y.detach() - y_plain).abs().max().item() < OUT_TOL           # same network, BatchNorm applied as (z - mean) * invstd * gamma + beta
+    running = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    (y * wgt.cuda()).sum().backward()
+    assert all(p.grad is None for p in m.parameters())                   # frozen when the forward ran
+    assert all(torch.equal(v, m.state_dict()[k]) for k, v in running.items())   # eval mode: running statistics untouched
+    # --- float64 arbiter ----------------------------------------------------------------------------------------------------------------
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    y64 = G.forward(sd64, x64, grad=True)
+    (y64 * wgt.double()).sum().backward()
+    assert (y.detach().cpu().double() - y64.detach()).abs().max().item() < OUT_TOL
+    sd32 = {k: v for k, v in sd.items()}
+    x32 = x.clone().requires_grad_(True)
+    (G.forward(sd32, x32, grad=True) * wgt).sum().backward()
+    spread = _rel(x32.grad.double(), x64.grad)                            # how far the reference arithmetic in fp32 is from float64 on this input
+    err = _rel(xg.grad.cpu().double(), x64.grad)
+    print(f"eval-mode generator dL/dx vs float64: {err:.2e} (torch-CPU fp32: {spread:.2e})")
+    assert err < max(GRAD_RTOL, 3 * spread)
+    # a second backward through the released tape fails loudly
+    with pytest.raises(RuntimeError, match="second time"):
+        (y * 1.0).sum().backward()
