@@ -132,11 +132,21 @@ __global__ __launch_bounds__(512) void maxpool_sq_lds_kernel(const float* __rest
     const int tiles = (H + MP_ROWS - 1) / MP_ROWS;
     const int b = blockIdx.x / tiles, y0 = (blockIdx.x % tiles) * MP_ROWS;
     const float* src = in + (size_t)b * H * W;
-    for (int i = threadIdx.x; i < NR * SW; i += 512) {
-        const int rr = i / SW, cx = i - rr * SW - R, y = y0 - R + rr;
-        float v = -INFINITY;
-        if (y >= 0 && y < H && cx >= 0 && cx < W) { v = src[(size_t)y * W + cx]; if (complement_in) v = 1.0f - v; }
-        A[i] = v;
+    // eight requests in flight per lane and trip, clamped addresses + select: a rolled load -> store loop pays one dependent global round trip per iteration (25 of them)
+    for (int base = 0; base < NR * SW; base += 512 * 8) {
+        float sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 512 * u + (int)threadIdx.x, rr = i / SW, cx = i - rr * SW - R, y = y0 - R + rr;
+            const bool in = i < NR * SW && y >= 0 && y < H && cx >= 0 && cx < W;
+            const float t = src[(size_t)min(max(y, 0), H - 1) * W + min(max(cx, 0), W - 1)];
+            sv[u] = in ? (complement_in ? 1.0f - t : t) : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 512 * u + (int)threadIdx.x;
+            if (i < NR * SW) A[i] = sv[u];
+        }
     }
     __syncthreads();
     const int W4 = (W + 3) / 4;

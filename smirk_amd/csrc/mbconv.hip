@@ -85,27 +85,47 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
 
     // ---- phase 0: halo tile of x -> LDS (zeros outside the image / beyond Cin / beyond NH); depthwise + BN constants -> LDS -----------
     {
-        const int P = a.cinp / 4, Preal = a.Cin / 4;
+        // Both staging loops request ALL of a lane's elements before the first one is stored: rolled load -> store loops pay one dependent global round trip per
+        // iteration (3-8 for the halo tile, 3-12 for the constants), which was most of a tile's ~10 us (24 k cycles for ~30 MFMAs; same defect and fix as the
+        // first version of encoder_head.hip).  Addresses are clamped and the value selected afterwards, so the loads carry no branches.
+        constexpr int P = KS * 4;                         // 16-byte vectors per staged row (cinp = 16 KS)
+        const int Preal = a.Cin / 4;
         const char* xb = a.x + (size_t)b * a.H * a.W * xrow;
-        for (int idx = tid; idx < MH * P; idx += 256) {
-            const int row = idx / P, pc = idx - row * P;
+        constexpr int NIT = (MH * P + 255) / 256;
+        f32x4 xv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it, row = idx / P, pc = idx - row * P;
             const int iy = iy0 + row / WI, ix = ix0 + row % WI;
-            const bool in = row < NH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (in && pc < Preal) v = *(const f32x4*)(xb + ((size_t)iy * a.W + ix) * xrow + pc * 16);
-            *(f32x4*)(Xs + row * strideX + pc * 16) = v;
-            if (pc == 0) ok[row] = in ? 1 : 0;
+            const bool in = idx < MH * P && row < NH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && pc < Preal;
+            const int yc = min(max(iy, 0), a.H - 1), xc = min(max(ix, 0), a.W - 1), pcc = min(pc, Preal - 1);
+            const f32x4 t = *(const f32x4*)(xb + ((size_t)yc * a.W + xc) * xrow + pcc * 16);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            xv[it] = in ? t : z;
         }
-        for (int idx = tid; idx < 13 * midp; idx += 256) {
-            const int k = idx / midp, ch = idx - k * midp;
-            float v = 0.f;
-            if (ch < a.mid) {
-                if (k < 9) v = a.wdw[k * a.mid + ch];
-                else if (k == 9) v = a.s2[ch];
-                else if (k == 10) v = a.b2[ch];
-                else if (EXP) v = (k == 11) ? a.s1[ch] : a.b1[ch];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it, row = idx / P, pc = idx - row * P;
+            if (idx < MH * P) {
+                const int iy = iy0 + row / WI, ix = ix0 + row % WI;
+                *(f32x4*)(Xs + row * strideX + pc * 16) = xv[it];
+                if (pc == 0) ok[row] = (row < NH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? 1 : 0;
             }
-            Wd[idx] = v;
+        }
+        for (int base = 0; base < 13 * midp; base += 256 * 4) {
+            float cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + 256 * u + tid, k = min(idx / midp, 12), ch = idx - (idx / midp) * midp, chc = min(ch, a.mid - 1);
+                const float* src = k < 9 ? a.wdw + (size_t)k * a.mid : k == 9 ? a.s2 : k == 10 ? a.b2 : (k == 11 ? (EXP ? a.s1 : a.s2) : (EXP ? a.b1 : a.b2));
+                const float t = src[chc];
+                cv[u] = (idx < 13 * midp && ch < a.mid && (k < 11 || EXP)) ? t : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + 256 * u + tid;
+                if (idx < 13 * midp) Wd[idx] = cv[u];
+            }
         }
     }
     mb_barrier();
@@ -122,6 +142,24 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
             }
         }
     }
+
+    // project-weight fragments of a chunk: fetched BEFORE the depthwise phase where the register budget allows (168 VGPRs at 3 workgroups per CU), so the
+    // L2 round trip hides under the depthwise arithmetic instead of sitting in front of the project MFMAs of every chunk
+    constexpr bool PREF = (P3 == 1);                    // stride 2: one project tile per wave (stride 1 with prefetch spilled 37-64 VGPRs)
+    half8 wpre[PREF ? P3 : 1][2][2];
+    auto load_wp = [&](int c, int q, half8 (*dst)[2]) {
+        const int id = wave + 4 * q;
+        const int nt = id - (id / ntn) * ntn, co = nt * 32 + fr;
+        const char* wrow = a.wproj + (size_t)(co < a.Cout ? co : 0) * a.mid * 4;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kg = min(4 * c + 2 * s + hb, a.mid / 8 - 1);
+            const bool v = id < ntiles && co < a.Cout && (4 * c + 2 * s + hb) * 8 < a.mid;
+            const half8 t0 = *(const half8*)(wrow + kg * 32), t1 = *(const half8*)(wrow + kg * 32 + 16);
+            dst[s][0] = v ? t0 : hz;
+            dst[s][1] = v ? t1 : hz;
+        }
+    };
 
     f32x16 pacc[P3][2];
 #pragma unroll
@@ -175,6 +213,10 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
             }
         }
         mb_barrier();
+        if constexpr (PREF) {
+#pragma unroll
+            for (int q = 0; q < P3; ++q) load_wp(c, q, wpre[q]);
+        }
         // ---- phase 2: depthwise 3x3 + BN + ReLU; a lane owns 4 consecutive channels of a pixel, 32 pixels per pass ------------------------
         {
             const int c4 = tid & 7, cb = 32 * c + c4 * 4;
@@ -215,24 +257,18 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
         for (int q = 0; q < P3; ++q) {
             const int id = wave + 4 * q;
             if (id < ntiles) {
-                const int mt = id / ntn, nt = id - mt * ntn, co = nt * 32 + fr;
+                const int mt = id / ntn;
                 const char* arow = Ds + (mt * 32 + fr) * DSB;
-                const char* wrow = a.wproj + (size_t)(co < a.Cout ? co : 0) * a.mid * 4;
-                half8 wp[2][2];                          // (the other resident workgroups of the CU cover this fetch)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int kg = 4 * c + 2 * s + hb;
-                    const bool v = co < a.Cout && kg * 8 < a.mid;
-                    wp[s][0] = v ? *(const half8*)(wrow + kg * 32) : hz;
-                    wp[s][1] = v ? *(const half8*)(wrow + kg * 32 + 16) : hz;
-                }
+                half8 wl[2][2];
+                if constexpr (!PREF) load_wp(c, q, wl);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int g = 2 * s + hb;
                     const half8 ah = *(const half8*)(arow + g * 32), al = *(const half8*)(arow + g * 32 + 16);
-                    pacc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wp[s][0], pacc[q][0], 0, 0, 0);
-                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wp[s][1], pacc[q][1], 0, 0, 0);
-                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wp[s][0], pacc[q][1], 0, 0, 0);
+                    const half8 w0 = PREF ? wpre[q][s][0] : wl[s][0], w1 = PREF ? wpre[q][s][1] : wl[s][1];
+                    pacc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w0, pacc[q][0], 0, 0, 0);
+                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w1, pacc[q][1], 0, 0, 0);
+                    pacc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w0, pacc[q][1], 0, 0, 0);
                 }
             }
         }

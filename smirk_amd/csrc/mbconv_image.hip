@@ -122,11 +122,23 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
     {
         const int P = a.Cin / 4;                         // 16-byte vectors per row
         const char* xb = a.x + (size_t)b0 * HW * xrow;
-        for (int idx = tid; idx < a.rows * P; idx += 512) {
-            const int row = idx / P, pc = idx - row * P;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < vrows) v = *(const f32x4*)(xb + (size_t)row * xrow + pc * 16);
-            *(f32x4*)(Xs + row * strideX + pc * 16) = v;
+        // four requests in flight per lane and trip (a rolled load -> store loop pays one dependent global round trip per 8 KB: 11 of them for 112 channels);
+        // the images of a workgroup are contiguous, so the copy is a linear stream re-strided to strideX; clamped address + select: no branches around the loads
+        const int total = a.rows * P, vtotal = vrows * P;
+        for (int base = 0; base < total; base += 512 * 4) {
+            f32x4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + 512 * u + tid;
+                const f32x4 t = *(const f32x4*)(xb + (size_t)min(idx, vtotal - 1) * 16);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                xv[u] = idx < vtotal ? t : z;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + 512 * u + tid, row = idx / P, pc = idx - row * P;
+                if (idx < total) *(f32x4*)(Xs + row * strideX + pc * 16) = xv[u];
+            }
         }
         for (int idx = tid; idx < a.gsz * 8; idx += 512) ((f32x4*)Es)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int r = tid; r < a.nb * 32; r += 512) {
