@@ -255,133 +255,6 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
     bn_backward_apply_body(z, dy, M, G, inv_n, mean, invstd, gamma, beta, sum_dy, sum_dy_xhat, relu, dz);
 }
 
-// ---- train-mode BatchNorm of SMALL tensors in ONE launch -----------------------------------------------------------------------------------------------
-// A training step runs 154 BatchNorm forwards and 120 backwards, three launches each; 86 + 64 of them are on the 14 x 14 / 7 x 7 stages (M = B H W <= 16 k
-// rows), where the tensor is a few MB and the three dependent launches (statistics over <= 512 blocks, 16-channels-per-block finalisation, element-wise pass)
-// cost more in launch gaps than in work.  Here ONE workgroup owns one 8-channel group: its 256 threads stride the M rows twice (statistics, then the
-// element-wise pass: the second read hits L2), the cross-thread reduction is two fixed-order stages in LDS (fp64: bit-reproducible, though not the same
-// summation order as the three-launch form), and no grid-wide synchronisation exists at all.  Grid = C / 8 workgroups.
-// (The cooperative one-launch form of round 2 — one grid for the whole tensor, two grid barriers — lost to three launches; this one has no barrier to lose to.)
-#define BN_SMALL_MAX_ROWS 16384
-template <int MODE>   // 0: forward (statistics of z, running-stat update, y);  1: backward (sums of dyh and dyh*xhat, dgamma / dbeta, dz)
-__global__ __launch_bounds__(256) void bn_small_kernel(const float* __restrict__ z, const float* __restrict__ dy, int M, int G, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ residual, int relu, float eps, float momentum,
-                                                       float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
-                                                       float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, float* __restrict__ out) {
-    __shared__ double red[256][16];
-    __shared__ double red2[16][16];
-    __shared__ float coef[4][8];
-    const int tid = threadIdx.x, g = blockIdx.x;
-    float ga[8], be[8], mu[8], is[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; mu[q] = 0.f; is[q] = 0.f; }
-    if (MODE == 1) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; }
-    }
-    double s1[8], s2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
-    // pass 1: four rows in flight per thread, row-ascending accumulation per thread
-    for (int r0 = tid; r0 < M; r0 += 4 * 256) {
-        float v[4][8], d[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 256 * u;
-            if (r < M) {
-                load_group(z + ((size_t)r * G + g) * 8, v[u]);
-                if (MODE == 1) load_group(dy + ((size_t)r * G + g) * 8, d[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r0 + 256 * u >= M) break;
-            if (MODE == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { s1[q] += (double)v[u][q]; s2[q] += (double)v[u][q] * (double)v[u][q]; }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float xh = (v[u][q] - mu[q]) * is[q];
-                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
-                    s1[q] += (double)dh; s2[q] += (double)dh * (double)xh;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { red[tid][q * 2] = s1[q]; red[tid][q * 2 + 1] = s2[q]; }
-    __syncthreads();
-    {   // stage A: thread (j, k) adds rows 16 j .. 16 j + 15 of column k in order; stage B: 16 threads add the 16 partials in order
-        const int j = tid >> 4, k = tid & 15;
-        double a = 0.0;
-        for (int r = 0; r < 16; ++r) a += red[j * 16 + r][k];
-        red2[j][k] = a;
-    }
-    __syncthreads();
-    if (tid < 8) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < 16; ++j) { a += red2[j][tid * 2]; b += red2[j][tid * 2 + 1]; }
-        const int c = g * 8 + tid;
-        if (MODE == 0) {
-            const double n = (double)M, m = a / n;
-            double v = b / n - m * m;
-            if (v < 0.0) v = 0.0;
-            const float inv = (float)(1.0 / sqrt(v + (double)eps));
-            mean[c] = (float)m; var[c] = (float)v; invstd[c] = inv;
-            if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
-            if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
-            coef[0][tid] = (float)m; coef[1][tid] = inv;
-        } else {
-            dbeta[c] = (float)a; dgamma[c] = (float)b;                     // S1 = sum dyh, S2 = sum dyh * xhat (colsum_stage2's out1 / out2)
-            coef[2][tid] = (float)a * (float)(1.0 / (double)M); coef[3][tid] = (float)b * (float)(1.0 / (double)M);
-        }
-    }
-    __syncthreads();
-    // pass 2: element-wise (the arithmetic of bn_apply_body / bn_backward_apply_body)
-    float c1[8], c2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { c1[q] = coef[MODE == 0 ? 0 : 2][q]; c2[q] = coef[MODE == 0 ? 1 : 3][q]; }
-    for (int r0 = tid; r0 < M; r0 += 4 * 256) {
-        float v[4][8], d[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 256 * u;
-            if (r < M) {
-                load_group(z + ((size_t)r * G + g) * 8, v[u]);
-                if (MODE == 1) load_group(dy + ((size_t)r * G + g) * 8, d[u]);
-                else if (residual) load_group(residual + ((size_t)r * G + g) * 8, d[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 256 * u;
-            if (r >= M) break;
-            if (MODE == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float t = (v[u][q] - c1[q]) * c2[q] * ga[q] + be[q];
-                    if (residual) t += d[u][q];
-                    v[u][q] = relu ? fmaxf(t, 0.f) : t;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float xh = (v[u][q] - mu[q]) * is[q];
-                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
-                    v[u][q] = ga[q] * is[q] * (dh - c1[q] - xh * c2[q]);
-                }
-            }
-            store_group(out + ((size_t)r * G + g) * 8, v[u]);
-        }
-    }
-}
-static bool bn_small_ok(size_t M, int C) {
-    const char* e = getenv("SMIRK_BN_SMALL");                         // "0": always the three-launch form (A/B switch; read per call: tests toggle it)
-    return !(e && e[0] == '0') && M <= BN_SMALL_MAX_ROWS && C >= 64;   // >= 8 workgroups; wider tensors at these sizes have 10-120
-}
-
 // 2x2/2 max-pool backward: the gradient goes to the first maximum of the window in scan order (ATen's max_pool2d picks `val > max`), plus an
 // optional second gradient of the same tensor (the U-Net skip connection) added in.  x, dx [B][H][W][G*8]; dy [B][H/2][W/2][G*8]
 __global__ __launch_bounds__(256) void maxpool_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ add,
@@ -1122,12 +995,6 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    if (bn_small_ok(M, C)) {
-        smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 4 : 3));
-        SMIRK_LAUNCH(bn_small_kernel<0>, dim3(G), dim3(256), 0, st, (const float*)z, (const float*)nullptr, (int)M, G, gamma, beta, (const float*)residual, relu,
-                     eps, momentum, save_mean, save_var, save_invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, (float*)y);
-        return smirk_launch_status();
-    }
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
@@ -1148,12 +1015,6 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    if (bn_small_ok(M, C)) {
-        smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 5);
-        SMIRK_LAUNCH(bn_small_kernel<1>, dim3(G), dim3(256), 0, st, (const float*)z, (const float*)dy, (int)M, G, gamma, beta, (const float*)nullptr, relu, 0.0f,
-                     0.0f, (float*)save_mean, (float*)nullptr, (float*)save_invstd, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (float*)dz);
-        return smirk_launch_status();
-    }
     const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
     SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);

@@ -380,37 +380,6 @@ def test_weight_packing_kernel_is_bitwise_the_torch_packing(cout, cin, k, off, s
     assert dgr.shape == want_d.shape and torch.equal(dgr.view(torch.int32), want_d.view(torch.int32))
 
 
-@pytest.mark.parametrize("shape,relu,res", [((64, 14, 14, 112), True, False), ((64, 7, 7, 960), False, True), ((5, 9, 11, 64), True, False)])
-def test_batchnorm_one_workgroup_per_group_form_agrees_with_three_launches(shape, relu, res):
-    """tensors of <= 16 k rows take bn_small_kernel (one launch, one workgroup per 8-channel group); $SMIRK_BN_SMALL=0 forces the three-launch form: the two
-    differ only in the order of the fp64 partial sums — agreement to fp32 round-off of the statistics, and both against float64"""
-    import os
-    T, ops = _ops()
-    B, H, W, C = shape
-    outs = []
-    for env in (None, "0"):
-        if env is not None:
-            os.environ["SMIRK_BN_SMALL"] = env
-        try:
-            torch.manual_seed(3)
-            g = _gen(C + H)
-            bn = torch.nn.BatchNorm2d(C).cuda().train()
-            with torch.no_grad():
-                bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
-            zs, z64 = _act(torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3)
-            rs = _act(torch.randn(B, H, W, C, generator=g))[0] if res else None
-            dys, _ = _act(torch.randn(B, H, W, C, generator=g))
-            y, mean, inv = ops.bn_forward(zs, bn, relu, residual=rs)
-            dz, dg, db = ops.bn_backward(zs, dys, bn, mean, inv, relu)
-            outs.append([t.clone() for t in (y, mean, inv, dz, dg, db, bn.running_mean, bn.running_var)])
-        finally:
-            if env is not None:
-                del os.environ["SMIRK_BN_SMALL"]
-    for a, b in zip(*outs):
-        fa, fb = (_val(a), _val(b)) if a.dim() == 4 else (a.cpu().double(), b.cpu().double())
-        assert _rel(fa, fb) < 2e-6
-
-
 def test_batchnorm_train_is_deterministic():
     """fixed-order fp64 partial sums: the BatchNorm forward / backward reproduce themselves bit for bit"""
     T, ops = _ops()
