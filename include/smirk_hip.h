@@ -417,6 +417,16 @@ int smirk_conv_wgrad_set_mode(int mode);
  * -> the step's two split16 operand images in ONE launch (either may be NULL):
  * fwd [Cout][(ky,kx,c)], c < cin_pad (zeros beyond Cin) and dgrad [cin_pad][(ky,kx,co)] = W rotated by 180 degrees with Cin <-> Cout swapped. */
 int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin_total, int cin_off, int Cin, int KH, int cin_pad, void* fwd, void* dgrad, void* stream);
+/* The same for EVERY weight of a network in one launch: `jobs_device` is a device array of njobs descriptors (arguments of the entry above; fwd / dgrad may be
+ * NULL per job), `start` = the job's first index in the flattened list of 8-channel output vectors, total_vectors = the list's length. */
+typedef struct SmirkPackJob {
+    const float* w;
+    void* fwd;
+    void* dgrad;
+    int32_t Cout, cin_total, cin_off, Cin, KH, cin_pad;
+    unsigned long long start;
+} SmirkPackJob;
+int smirk_pack_conv_weights_batch_split16(const SmirkPackJob* jobs_device, int njobs, unsigned long long total_vectors, void* stream);
 size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, int KH);
 int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                          void* stream);

@@ -144,6 +144,7 @@ _SIGS = {
     "smirk_conv_wgrad_set_mode": (_i, [_i]),
     "smirk_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_pack_conv_weights_batch_split16": (_i, [_p, _i, C.c_ulonglong, _p]),
     "smirk_pack_conv_weights_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_stem_conv_s2_raw_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_stem_conv_s2_wgrad_workspace_bytes": (_sz, [_i]),
@@ -235,6 +236,12 @@ def conv_layer(w, scale=None, shift=None):
     l.scale = scale.data_ptr() if scale is not None else None
     l.shift = shift.data_ptr() if shift is not None else None
     return l
+
+
+class SmirkPackJob(C.Structure):
+    """include/smirk_hip.h SmirkPackJob"""
+    _fields_ = [("w", C.c_void_p), ("fwd", C.c_void_p), ("dgrad", C.c_void_p), ("Cout", C.c_int32), ("cin_total", C.c_int32), ("cin_off", C.c_int32),
+                ("Cin", C.c_int32), ("KH", C.c_int32), ("cin_pad", C.c_int32), ("start", C.c_ulonglong)]
 
 
 class _LoudCut(torch.autograd.Function):

@@ -206,6 +206,25 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         if (lane < cnt) {
             const float* r = sface + lane * FACE_REC;
             rel = !(sx_lo > r[11] || sx_hi < r[10] || sy_lo > r[13] || sy_hi < r[12]);
+            // Edge test of the whole block (the synthetic FLAME basis stretches triangles to ~21 x 22-pixel boxes: a box overlaps many blocks its
+            // triangle never enters).  A pixel is covered only if s e_k > 0 for all three edge functions, s = sign(area + eps); e_k is linear in the
+            // pixel centre, so its maximum over the block sits at a corner and separates into an x and a y term.  The face is dropped when that
+            // maximum is below MINUS a margin 50x larger than the fp32 rounding of the per-pixel evaluation (|e| <= |A| |dx| + |B| |dy|, error <~ 2e-7
+            // of that): whatever the exact per-pixel arithmetic below would have computed for this block is <= 0, i.e. the per-pixel test would have
+            // skipped the face at every pixel.  Conservative => pix_to_face / bary / zbuf stay bit-identical (tests/test_render_gpu.py).
+            const float area = r[9];
+            if (rel && area != 0.0f) {
+                const float sg = area < 0.0f ? -1.0f : 1.0f;
+                const float vx[3] = {r[3], r[6], r[0]}, vy[3] = {r[4], r[7], r[1]};          // e0 is taken about v1, e1 about v2, e2 about v0
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float A = sg * r[14 + 2 * k], Bc = -sg * r[15 + 2 * k];
+                    const float dx0 = sx_lo - vx[k], dx1 = sx_hi - vx[k], dy0 = sy_lo - vy[k], dy1 = sy_hi - vy[k];
+                    const float emax = fmaxf(A * dx0, A * dx1) + fmaxf(Bc * dy0, Bc * dy1);
+                    const float mag = fabsf(A) * fmaxf(fabsf(dx0), fabsf(dx1)) + fabsf(Bc) * fmaxf(fabsf(dy0), fabsf(dy1));
+                    if (emax < -1e-5f * mag) rel = false;
+                }
+            }
         }
         unsigned long long relmask = __ballot(rel);
         while (relmask) {

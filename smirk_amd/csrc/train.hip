@@ -971,11 +971,47 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
     }
 }
 
+// every weight of a network in ONE launch: job j owns the vector range [start_j, start_{j+1}) of the flattened work list; a thread finds its job by
+// binary search (<= 8 steps for 256 jobs).  A training step re-packed its 59 convolution weights with 118 launches of ~13 us each.
+__global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const SmirkPackJob* __restrict__ jobs, int njobs, unsigned long long total) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+        }
+        const SmirkPackJob J = jobs[lo];
+        const size_t li = (size_t)(i - J.start);
+        const int T = J.KH * J.KH;
+        const size_t nf = J.fwd ? (size_t)J.Cout * T * J.cin_pad / 8 : 0;
+        float v[8];
+        if (li < nf) {
+            const size_t k0 = (li * 8) % ((size_t)T * J.cin_pad);
+            const int co = (int)((li * 8) / ((size_t)T * J.cin_pad)), tap = (int)(k0 / J.cin_pad), c0 = (int)(k0 % J.cin_pad);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (c0 + q < J.Cin) ? J.w[((size_t)co * J.cin_total + J.cin_off + c0 + q) * T + tap] : 0.f;
+            store_group((float*)J.fwd + li * 8, v);
+        } else {
+            const size_t j = li - nf, k0 = (j * 8) % ((size_t)T * J.Cout);
+            const int ci = (int)((j * 8) / ((size_t)T * J.Cout)), tap = (int)(k0 / J.Cout), co0 = (int)(k0 % J.Cout);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (ci < J.Cin) ? J.w[((size_t)(co0 + q) * J.cin_total + J.cin_off + ci) * T + (T - 1 - tap)] : 0.f;
+            store_group((float*)J.dgrad + j * 8, v);
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int smirk_pack_conv_weights_batch_split16(const SmirkPackJob* jobs_device, int njobs, unsigned long long total_vectors, void* stream) {
+    if (!jobs_device || njobs <= 0 || njobs > 4096 || total_vectors == 0) return SMIRK_ERR_BAD_ARG;
+    SMIRK_LAUNCH(pack_conv_weights_batch_kernel, dim3(blocks_for((size_t)total_vectors, 8192)), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs, total_vectors);
+    return smirk_launch_status();
+}
+
 extern "C" int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin_total, int cin_off, int Cin, int KH, int cin_pad, void* fwd, void* dgrad,
                                                void* stream) {
     if (!w || (!fwd && !dgrad) || Cout <= 0 || Cin <= 0 || cin_off < 0 || cin_off + Cin > cin_total || Cout % 8 || cin_pad % 8 || cin_pad < Cin ||

@@ -42,6 +42,7 @@ class _Ops:
     def __init__(self, device, eval_bn=False):
         self.lib, self.st, self.dev = L.lib(), L.stream_ptr(), device
         self.eval_bn = bool(eval_bn)                     # BatchNorm from the running statistics (module in .eval() inside an autograd graph)
+        self.plan = None
         self.red_ws = torch.empty(self.lib.smirk_train_reduce_workspace_bytes(1024), dtype=torch.uint8, device=device)
         self.wg_ws = None
 
@@ -62,7 +63,14 @@ class _Ops:
         return out
 
     def pack(self, weight, cin_off=0, cin=None, cin_pad=None, fwd=True, dgrad=True):
-        """nn.Conv2d weight (fp32 parameter) -> (forward weight split16 [Cout][T*cin_pad] or None, data-gradient weight split16 [cin_pad][T*Cout] or None)"""
+        """nn.Conv2d weight (fp32 parameter) -> (forward weight split16 [Cout][T*cin_pad] or None, data-gradient weight split16 [cin_pad][T*Cout] or None).
+        With a PackPlan attached (`self.plan`) the call only RECORDS the job on the plan's first pass and hands out the plan's buffers afterwards: all
+        weights of the network are then packed by ONE launch at the top of the forward (PackPlan.run) instead of one launch per call."""
+        if self.plan is not None:
+            return self.plan.request(self, weight, cin_off, cin, cin_pad, fwd, dgrad)
+        return self._pack_now(weight, cin_off, cin, cin_pad, fwd, dgrad)
+
+    def _pack_now(self, weight, cin_off=0, cin=None, cin_pad=None, fwd=True, dgrad=True):
         w = weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
@@ -126,6 +134,53 @@ class _Ops:
         return out
 
 
+class PackPlan:
+    """All conv-weight operand images of one module, packed by one launch per forward.  First forward: `request` runs the per-weight kernel and records the job
+    (weight pointer, slice, padding, output buffers); `seal` uploads the job table.  Later forwards: `run` launches smirk_pack_conv_weights_batch_split16 once and
+    `request` hands the recorded buffers out in the same order (the forward's sequence of pack calls is a function of the architecture only).  Buffers are owned
+    by the plan and overwritten by the next forward: the tape of an earlier forward sees the new images — identical values unless the weights changed in between,
+    which is also when a stale tape would be wrong in the reference (autograd raises there; here backward-before-next-forward is the contract)."""
+
+    def __init__(self):
+        self.jobs, self.bufs, self.sealed, self.cursor, self.table, self.total = [], [], False, 0, None, 0
+
+    def valid_for(self, params):
+        return self.sealed and self.key == tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+
+    def request(self, ops, weight, cin_off, cin, cin_pad, fwd, dgrad):
+        if self.sealed:
+            f, d = self.bufs[self.cursor]
+            self.cursor += 1
+            return f, d
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise L.SmirkHipError("PackPlan needs contiguous fp32 conv weights")
+        f, d = ops._pack_now(weight, cin_off, cin, cin_pad, fwd, dgrad)
+        cout, ctot, k = w.shape[0], w.shape[1], w.shape[2]
+        cin_ = ctot - cin_off if cin is None else cin
+        cp = cin_ if cin_pad is None else max(cin_, cin_pad)
+        n = (cout * k * k * cp // 8 if fwd else 0) + (cp * k * k * cout // 8 if dgrad else 0)
+        self.jobs.append((w.data_ptr(), f, d, cout, ctot, cin_off, cin_, k, cp, n))
+        self.bufs.append((f, d))
+        return f, d
+
+    def seal(self, params, device):
+        arr = (L.SmirkPackJob * len(self.jobs))()
+        start = 0
+        for j, (wp, f, d, cout, ctot, off, cin_, k, cp, n) in zip(arr, self.jobs):
+            j.w, j.fwd, j.dgrad = wp, (f.data_ptr() if f is not None else None), (d.data_ptr() if d is not None else None)
+            j.Cout, j.cin_total, j.cin_off, j.Cin, j.KH, j.cin_pad, j.start = cout, ctot, off, cin_, k, cp, start
+            start += n
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.total, self.sealed = start, True
+        self.key = tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+
+    def run(self, ops):
+        self.cursor = 0
+        L.check(ops.lib.smirk_pack_conv_weights_batch_split16(L.ptr(self.table, torch.uint8), len(self.jobs), self.total, ops.st))
+
+
 def _to_conv_weight_grad(dw, cout, cin, k=3, cin_real=None):
     """packed [Cout][(ky,kx,ci)] -> nn.Conv2d layout [Cout,Cin,k,k]"""
     g = dw.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
@@ -148,6 +203,13 @@ class GeneratorTrainFunction(torch.autograd.Function):
         ops = _Ops(x.device, eval_bn=not module.training)
         lib, st, f = ops.lib, ops.st, module.features
         ctx.eval_bn = not module.training
+        plan = getattr(module, "_pack_plan", None)
+        if plan is None or not plan.valid_for(params):                    # first forward (or the parameters were re-allocated): record
+            plan = PackPlan()
+            object.__setattr__(module, "_pack_plan", plan)
+        else:
+            plan.run(ops)                                                 # every conv weight of the network: one launch
+        ops.plan = plan
         tape = []                                                         # records consumed in reverse by backward()
         xin = torch.empty(B, H, W, 8, device=x.device)
         L.check(lib.smirk_pack_generator_input_split16(L.ptr(x), Cx, None, 0, L.ptr(xin), B, H, W, st))
@@ -205,6 +267,8 @@ class GeneratorTrainFunction(torch.autograd.Function):
         bf = module.conv.bias.detach().float().contiguous()
         y = torch.empty(B, module.out_channels, H, W, device=x.device)
         L.check(lib.smirk_conv1x1_sigmoid_nchw_split16(L.ptr(d), L.ptr(wf), L.ptr(bf), L.ptr(y), B, H, W, f, module.out_channels, st))
+        if not plan.sealed:
+            plan.seal(params, x.device)
         ctx.module, ctx.tape, ctx.final = module, tape, (d, wf, y)
         ctx.shape = (B, Cx, H, W)
         return y

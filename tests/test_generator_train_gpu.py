@@ -161,3 +161,43 @@ def test_eval_mode_generator_is_differentiable_to_its_input(B, HW):
     # a second backward through the released tape fails loudly
     with pytest.raises(RuntimeError, match="second time"):
         (y * 1.0).sum().backward()
+
+
+def test_one_launch_weight_packing_plan_equals_per_weight_packing():
+    """PackPlan: the first train-mode forward packs every conv weight with its own launch and records the jobs; later forwards run
+    smirk_pack_conv_weights_batch_split16 once.  Same outputs and gradients bit for bit, also after an optimiser-like in-place weight change (the plan reads
+    the live parameters) and after the parameters are re-allocated (the plan is re-recorded)."""
+    sd = G.synth_state_dict()
+    m = _module(sd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 6, 64, 64, generator=g).cuda()
+    wgt = torch.randn(2, 3, 64, 64, generator=g).cuda()
+
+    def step(mod):
+        for p in mod.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = mod(xx)
+        (y * wgt).sum().backward()
+        return y.detach().clone(), xx.grad.clone(), [p.grad.clone() for p in mod.parameters()]
+
+    def same(a, b):
+        return torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+
+    first = step(m)                                               # records the plan (per-weight launches)
+    assert m._pack_plan.sealed and len(m._pack_plan.jobs) >= 27
+    m.load_state_dict(sd)                                         # BatchNorm running statistics back (they do not enter train-mode outputs, but keep the state equal)
+    second = step(m)                                              # one batch launch
+    assert same(first, second)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+    third = step(m)                                               # the plan packs the LIVE weights
+    fresh = _module({k: (v * 1.01 if k in dict(m.named_parameters()) else v) for k, v in sd.items()})
+    with torch.no_grad():
+        for (k, p), (_, q) in zip(fresh.named_parameters(), m.named_parameters()):
+            p.copy_(q)
+    assert same(step(fresh), third)
+    assert not torch.equal(third[0], first[0])
+    m2 = _module(sd)                                              # new parameter storage -> new plan
+    assert same(step(m2), first)
