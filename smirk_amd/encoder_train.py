@@ -82,6 +82,14 @@ class BackboneTrainFunction(torch.autograd.Function):
             raise L.SmirkHipError("SmirkEncoder: expected [B, 3, H >= 32, W >= 32] images")
         ops = _EncOps(img.device)
         lib, st = ops.lib, ops.st
+        from .generator_train import PackPlan
+        plan = getattr(backbone, "_pack_plan", None)                      # every pointwise weight of the backbone: one packing launch per forward
+        if plan is None or not plan.valid_for(params):
+            plan = PackPlan()
+            object.__setattr__(backbone, "_pack_plan", plan)
+        else:
+            plan.run(ops)
+        ops.plan = plan
         tape = []
         c0 = backbone.conv_stem.out_channels
         wst = backbone.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(c0, 27).contiguous()
@@ -126,6 +134,8 @@ class BackboneTrainFunction(torch.autograd.Function):
         if clamp_n_exp >= 0:
             out = raw.clone()
             L.check(lib.smirk_expression_clamps(L.ptr(out), B, clamp_n_exp, st))
+        if not plan.sealed:
+            plan.seal(params, img.device)
         ctx.backbone, ctx.head, ctx.tape = backbone, head, tape
         ctx.headrec = (hw_, pooled, raw, clamp_n_exp, (B, hf, wf, Cf, N))
         ctx.img_shape = (B, H, W)

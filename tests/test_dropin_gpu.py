@@ -111,12 +111,21 @@ def test_trainer_call_patterns(in_sandbox):
     with torch.no_grad():
         y = t.smirk_generator(A.synth_generator_input(1, seed=2).cuda())
     assert y.shape == (1, 3, 224, 224)
-    # differentiating through the forward-only CNNs must fail loudly, never silently drop the gradient
+    # smirk_trainer.py:108-113: the frozen, eval-mode generator INSIDE the autograd graph — the loss reaches its input, no parameter gets a gradient
     x = A.synth_generator_input(1, seed=2).cuda().requires_grad_(True)
     out = t.smirk_generator(x)
-    assert out.requires_grad
+    assert out.requires_grad and (out.detach() - y).abs().max().item() < 2e-5
+    out.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    assert all(p.grad is None for p in t.smirk_generator.parameters())
+    # differentiating through a forward-only CNN must fail loudly, never silently drop the gradient: the eval-mode encoder has no backward
+    t.smirk_encoder.eval()
+    for p in t.smirk_encoder.parameters():
+        p.requires_grad_(True)
+    eo = t.smirk_encoder(A.synth_images(1, seed=3).cuda().requires_grad_(True))
+    assert eo["expression_params"].requires_grad
     with pytest.raises(NotImplementedError):
-        out.sum().backward()
+        eo["expression_params"].sum().backward()
 
 
 def test_renderer_full_head_returns_the_shifted_z(in_sandbox):
