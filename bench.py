@@ -80,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
     ap.add_argument("--cpu-faces", type=int, default=24, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU baseline with os.cpu_count() threads (takes ~15 min on a 256-thread host: the sample is too small for that many threads)")
     ap.add_argument("--traffic", choices=("measure", "file", "off"), default=None,
                     help="roofline.traffic: run two rocprofv3 --pmc passes of this script (default at 1 GPU), read profiles/pmc_traffic.json, or skip")
     ap.add_argument("--no-roofline", action="store_true")
@@ -161,14 +163,19 @@ def output_stats(out):
 # ------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle = a port of the reference path; checker code, timed beside the GPU on a bounded sample)
 # ------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sandbox, workload, n_faces, threads=None):
-    """threads=None: the 32-thread measurement (more threads than that only thrash on the bounded sample) PLUS, under "all_cores", the same sample
-    with torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 asks; threads=N: that thread count only."""
+def cpu_baseline(sandbox, workload, n_faces, threads=None, all_cores=False):
+    """threads=None: the 32-thread measurement.  all_cores=True (--cpu-all-cores) adds, under "all_cores", the same sample with
+    torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 asks - opt-in, because on the 256-thread GPU host that leg oversubscribes
+    the torch-CPU convolutions of a 24-frame sample so badly (0.19 faces/s against 7.8 at 32 threads: profiles/r03z_bench_full.json) that it
+    alone takes 15 minutes.  threads=N: that thread count only."""
     if threads is None:
         base = cpu_baseline(sandbox, workload, n_faces, threads=min(os.cpu_count(), 32))
-        if os.cpu_count() > base["cores"]:
+        if all_cores and os.cpu_count() > base["cores"]:
             allc = cpu_baseline(sandbox, workload, n_faces, threads=os.cpu_count())
             base["all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "stage_seconds", "sample")}
+        elif os.cpu_count() > base["cores"]:
+            base["all_cores"] = ("not run by default (opt in with --cpu-all-cores); measured on the 256-thread MI355X host in round 3: 0.19 faces/s (full), "
+                                 "0.24 faces/s (infer256) at 256 threads against 7.8 / 11.8 at 32 - profiles/r03z_bench_full.json, r03z_bench_infer256.json")
         return base
     import numpy as np
     import torch
@@ -737,7 +744,7 @@ def main():
         value = faces / dt
         cpu = None
         if world == 1 and args.cpu_faces > 0 and not args.plumbing_test:
-            cpu = cpu_baseline(sandbox, args.workload, args.cpu_faces if args.workload != "flame512" else 512)
+            cpu = cpu_baseline(sandbox, args.workload, args.cpu_faces if args.workload != "flame512" else 512, all_cores=args.cpu_all_cores)
         weak = args.batch is not None or (args.workload == "train64" and args.global_batch is None)
         flop_face = {"full": FLOP_PER_FACE, "infer256": FLOP_PER_FACE_INFER, "flame512": FLOP_PER_FACE_FLAME, "train64": FLOP_PER_FACE_TRAIN}[args.workload]
         gen_prec = getattr(getattr(wl, "gen", None), "precision", None)
