@@ -611,7 +611,9 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
                 "traffic": traffic, "flop_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n if by else None,
                 "mfma_issue_frac": (3.0 if split else 1.0) * fl / tm / peak,
                 "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per product "
-                         "(hi.hi, hi.lo, lo.hi), so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA") if split else
+                         "(hi.hi, hi.lo, lo.hi), so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA at the nominal 2.4 GHz - a separate "
+                         "GRBM_GUI_ACTIVE pass (tools/pmc_clock.py, profiles/r03u_pmc_clock_full.txt; not re-measured by this run) found the deep-layer kernel "
+                         "running at 1.62 GHz under the power cap with its matrix pipe 0.81 busy at that clock") if split else
                         "achieved = algorithmic flop per launch / HIP-event launch time; peak = f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
     else:
         roof = {"bound": "hbm", "kernel": dom, "achieved": by / tm / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by / tm / PEAK_HBM,
