@@ -41,12 +41,26 @@ struct EncHeadArgs {
     int B, H, W, Hs, Ws, Ho, Wo, residual, tiles_x, tiles_y, pts, pls, ptd, pld;
 };
 
+// float offsets of 16-byte quad `quad` of halo position q (column hx) in Ss, and of output pixel p in Ds (see the layout notes in the kernel)
+__device__ __forceinline__ int ss_off(int q, int hx, int quad) { return q * 16 + ((quad ^ ((hx >> 1) & 3)) << 2); }
+__device__ __forceinline__ int ds_off(int p, int quad) { return p * 16 + ((quad ^ ((p + (p >> 2)) & 3)) << 2); }
+
 template <int S>
 __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs a) {
     constexpr int TO = (S == 1) ? 16 : 8;               // output tile
     constexpr int TS = (TO - 1) * S + 3;                // stem-image halo tile (18 | 17)
     constexpr int TI = (TS - 1) * 2 + 3;                // image patch (37 | 35)
-    constexpr int TIP = TI + 1;                         // LDS row stride of the patch
+    // LDS layouts (bank rules of MI355X_MICROARCH.md: ds_read_b32 = 2 x 32 lanes over 32 banks; ds_read_b128 = the lane groups {0-3, 12-15, 20-27} /
+    // {4-11, 16-19, 28-31} over 64 banks; ds_write_b128 = 8 x 8 lanes over 32 banks).  Round 3's census (profiles/r03v_pmc_census_full.txt) found 65 % of this
+    // kernel's LDS cycles in bank conflicts: the stem's stride-2 reads were 2-way, every [pixel][16-float] access 4- to 8-way (a pixel is 64 bytes, so 16 lanes
+    // only reach 4 of the 16 16-byte bank slots).
+    //   image patch, stride-1 variant: columns split into an even and an odd plane per row (tap kx reads plane kx & 1 at x + (kx >> 1): consecutive lanes ->
+    //     consecutive banks) and a row pitch of 41 (2 * 41 = 18 mod 32: the lanes that wrap into the next stem row continue on the next banks): conflict-free;
+    //   Ss [halo pixel][16]: the 16-byte quad is XOR-swizzled with (column >> 1) & 3: depthwise tap reads conflict-free at stride 1, 2-way at stride 2 (was 4 / 8);
+    //   Ds [pixel][16]: quad ^ ((p + (p >> 2)) & 3): pointwise reads and depthwise writes conflict-free (were 4-way).
+    constexpr bool SPLIT = (S == 1);
+    constexpr int TIP = SPLIT ? 41 : TI + 1;            // LDS row stride of the patch
+    constexpr int HALF = 21;                            // SPLIT: offset of the odd-column plane inside a row (even plane: 19 entries)
     constexpr int ISZ = 3 * TI * TIP, DSZ = TO * TO * 16;
     __shared__ __attribute__((aligned(16))) float IDs[ISZ > DSZ ? ISZ : DSZ];   // image patch [c][y][x]; dead after phase B, then the depthwise output [p][16]
     __shared__ __attribute__((aligned(16))) float Ss[TS * TS * 16];   // stem output [y][x][16]
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + 256 * it;
             const int c = i / (TI * TI), r = i - c * TI * TI, y = r / TI, x = r - y * TI;
-            if (i < 3 * TI * TI) Is[(c * TI + y) * TIP + x] = v[it];
+            if (i < 3 * TI * TI) Is[(c * TI + y) * TIP + (SPLIT ? (x & 1) * HALF + (x >> 1) : x)] = v[it];
         }
         {   // thread = (cout, cin): split16 row of cout, group cin / 8, element cin % 8
             const int co = tid >> 4, ci = tid & 15;
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
         for (int j = 0; j < NP; ++j) {
             const int p = min((tid & 127) + 128 * j, TS * TS - 1);   // clamped lanes recompute the last pixel; they do not store
             const int y = p / TS, x = p - y * TS;
-            base[j] = 2 * y * TIP + 2 * x;
+            base[j] = 2 * y * TIP + (SPLIT ? x : 2 * x);
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[j][q] = 0.f;
         }
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
                     for (int q = 0; q < 8; ++q) wq[q] = wk[q * 27 + kx * 3 + c];
 #pragma unroll
                     for (int j = 0; j < NP; ++j) {
-                        const float v = Is[c * TI * TIP + base[j] + ky * TIP + kx];
+                        const float v = Is[c * TI * TIP + base[j] + ky * TIP + (SPLIT ? (kx & 1) * HALF + (kx >> 1) : kx)];
 #pragma unroll
                         for (int q = 0; q < 8; ++q) acc[j][q] = fmaf(v, wq[q], acc[j][q]);
                     }
@@ -146,8 +160,8 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
                     o0[q] = in ? fmaxf(acc[j][q] * sc[q] + sh[q], 0.f) : 0.f;
                     o1[q] = in ? fmaxf(acc[j][4 + q] * sc[4 + q] + sh[4 + q], 0.f) : 0.f;
                 }
-                *(f32x4*)(Ss + p * 16 + half * 8) = o0;
-                *(f32x4*)(Ss + p * 16 + half * 8 + 4) = o1;
+                *(f32x4*)(Ss + ss_off(p, x, 2 * half)) = o0;
+                *(f32x4*)(Ss + ss_off(p, x, 2 * half + 1)) = o1;
             }
         }
     }
@@ -167,13 +181,13 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const f32x4 v = *(const f32x4*)(Ss + ((y * S + ky) * TS + x * S + kx) * 16 + quad * 4);
+                    const f32x4 v = *(const f32x4*)(Ss + ss_off((y * S + ky) * TS + x * S + kx, x * S + kx, quad));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[q], w[(ky * 3 + kx) * 16 + q], acc[q]);
                 }
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = fmaxf(acc[q] * sc[q] + sh[q], 0.f);
-            *(f32x4*)(Ds + p * 16 + quad * 4) = acc;
+            *(f32x4*)(Ds + ds_off(p, quad)) = acc;
         }
     }
     __syncthreads();
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 v = *(const f32x4*)(Ds + p * 16 + c4 * 4);
+                const f32x4 v = *(const f32x4*)(Ds + ds_off(p, c4));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 w0 = *(const f32x4*)(Wp + (c4 * 4 + k) * 16 + half * 8), w1 = *(const f32x4*)(Wp + (c4 * 4 + k) * 16 + half * 8 + 4);
@@ -202,8 +216,8 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] = acc[q] * sc[q] + sh[q];
             if (a.residual) {                                        // stride 1: x of the block = S at the same pixel = halo position (y + ptd, x + pld)
-                const float* s = Ss + ((y + a.ptd) * TS + x + a.pld) * 16 + half * 8;
-                const f32x4 r0 = *(const f32x4*)s, r1 = *(const f32x4*)(s + 4);
+                const int rq = (y + a.ptd) * TS + x + a.pld;
+                const f32x4 r0 = *(const f32x4*)(Ss + ss_off(rq, x + a.pld, 2 * half)), r1 = *(const f32x4*)(Ss + ss_off(rq, x + a.pld, 2 * half + 1));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { acc[q] += r0[q]; acc[4 + q] += r1[q]; }
             }

@@ -121,11 +121,15 @@ __global__ __launch_bounds__(256) void maxfilter1d_kernel(const float* __restric
 // instead of 21 global ones), then the y pass the same way down a column (lanes are neighbouring x: conflict-free) and writes the result.
 // max is exact and order-free, so the output equals the two-pass form bit for bit (tests/test_masking_gpu.py).
 #define MP_ROWS 32
+__host__ __device__ static inline int mp_row_stride(int W, int R) { return (W + 3) / 4 * 4 + (2 * R + 3) / 4 * 4 + 4; }
 template <int R>
 __global__ __launch_bounds__(512) void maxpool_sq_lds_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                             int complement_in, int complement_out) {
-    extern __shared__ float mp_lds[];
-    const int SW = W + 2 * R;                           // staged row stride (margins included)
+    extern __shared__ __attribute__((aligned(16))) float mp_lds[];
+    // staged row stride: the W + 2R columns (margins included) rounded up so that every thread's 4 + 2R window, read as whole 16-byte vectors, stays inside its
+    // row.  The x pass reads the window of a lane with ds_read_b128 (lane stride 16 bytes: conflict-free); as scalar reads at a lane stride of 4 floats every
+    // access was a 4-way bank conflict - 58-64 % of this kernel's LDS cycles (profiles/r03v_pmc_census_full.txt).
+    const int SW = mp_row_stride(W, R);
     const int NR = MP_ROWS + 2 * R;                     // staged rows
     float* A = mp_lds;                                  // [NR][SW]  input rows
     float* Hx = mp_lds + NR * SW;                       // [NR][W]   after the x pass
@@ -152,10 +156,14 @@ __global__ __launch_bounds__(512) void maxpool_sq_lds_kernel(const float* __rest
     const int W4 = (W + 3) / 4;
     for (int i = threadIdx.x; i < NR * W4; i += 512) {
         const int rr = i / W4, x = (i - rr * W4) * 4;
-        const float* a = A + rr * SW + x;              // a[k] = column x - R + k
-        float v[4 + 2 * R];
+        const f32x4* a4 = (const f32x4*)(A + rr * SW + x);   // a[k] = column x - R + k; 16-byte aligned: SW and x are multiples of 4
+        constexpr int NV = (4 + 2 * R + 3) / 4;
+        float v[4 * NV];
 #pragma unroll
-        for (int k = 0; k < 4 + 2 * R; ++k) v[k] = (x + k < SW) ? a[k] : -INFINITY;
+        for (int j = 0; j < NV; ++j) {
+            const f32x4 t = a4[j];
+            v[4 * j] = t[0]; v[4 * j + 1] = t[1]; v[4 * j + 2] = t[2]; v[4 * j + 3] = t[3];
+        }
         float c = v[3];
 #pragma unroll
         for (int k = 4; k <= 2 * R; ++k) c = fmaxf(c, v[k]);
@@ -164,10 +172,15 @@ __global__ __launch_bounds__(512) void maxpool_sq_lds_kernel(const float* __rest
         const float o2 = fmaxf(fmaxf(c, v[2]), fmaxf(v[2 * R + 2], v[2 * R + 1]));
         const float o3 = fmaxf(fmaxf(c, v[2 * R + 3]), fmaxf(v[2 * R + 2], v[2 * R + 1]));
         float* h = Hx + rr * W + x;
-        h[0] = o0;
-        if (x + 1 < W) h[1] = o1;
-        if (x + 2 < W) h[2] = o2;
-        if (x + 3 < W) h[3] = o3;
+        if ((W & 3) == 0) {                             // uniform: rows of Hx are 16-byte aligned
+            const f32x4 o = {o0, o1, o2, o3};
+            *(f32x4*)h = o;
+        } else {
+            h[0] = o0;
+            if (x + 1 < W) h[1] = o1;
+            if (x + 2 < W) h[2] = o2;
+            if (x + 3 < W) h[3] = o3;
+        }
     }
     __syncthreads();
     float* dst = out + (size_t)b * H * W;
@@ -322,7 +335,7 @@ extern "C" int smirk_points_to_pixels(const float* points, int B, int L, int ima
 
 template <int R>
 static void launch_maxpool_lds(const float* in, float* out, int B, int H, int W, int complement, hipStream_t st) {
-    const size_t lds = ((size_t)(MP_ROWS + 2 * R) * (W + 2 * R) + (size_t)(MP_ROWS + 2 * R) * W) * sizeof(float);
+    const size_t lds = (size_t)(MP_ROWS + 2 * R) * ((size_t)mp_row_stride(W, R) + W) * sizeof(float);
     static bool attr_done[64] = {};                    // per device: the attribute is per-device state (one process may drive several GPUs)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -339,7 +352,7 @@ extern "C" int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, 
     if (!in || !tmp || !out || B <= 0 || H <= 0 || W <= 0 || radius < 0) return SMIRK_ERR_BAD_ARG;
     const size_t n = (size_t)B * H * W;
     // the fused LDS form covers the radii the reference uses (masking.py:78 -> 10, :96 -> 5) at widths whose staged rows fit 160 KB of LDS
-    const size_t staged = (size_t)(MP_ROWS + 2 * radius) * (2 * (size_t)W + 2 * radius) * sizeof(float);
+    const size_t staged = (size_t)(MP_ROWS + 2 * radius) * ((size_t)W + mp_row_stride(W, radius)) * sizeof(float);
     const bool lds_ok = staged <= 160 * 1024 && (size_t)B * ((H + MP_ROWS - 1) / MP_ROWS) < 0x7fffffffull;
     if (lds_ok && radius == 10) { launch_maxpool_lds<10>(in, out, B, H, W, complement, (hipStream_t)stream); return smirk_launch_status(); }
     if (lds_ok && radius == 5) { launch_maxpool_lds<5>(in, out, B, H, W, complement, (hipStream_t)stream); return smirk_launch_status(); }
