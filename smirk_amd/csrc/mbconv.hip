@@ -20,7 +20,10 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#define MB_ES(S) ((S) == 1 ? 32 : 36)
+#ifndef MB_ES2
+#define MB_ES2 36                 // stride-2 E row stride; 48 is the conflict-free value (variant build: tools/build_variant.sh "-DMB_ES2=48" mbconv.hip)
+#endif
+#define MB_ES(S) ((S) == 1 ? 32 : MB_ES2)
 
 struct MBArgs {
     const char* x;          // split16 NHWC, Cin*4 bytes per pixel

@@ -9,7 +9,7 @@ mkdir -p $OUT
 objs=""
 for s in smirk_amd/csrc/*.hip; do
   b=$(basename $s .hip)
-  flags="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function"
+  flags="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -fno-slp-vectorize -fno-vectorize"   # = smirk_amd/build.py COMMON
   case $b in render|video) flags="$flags -ffp-contract=off";; esac
   for v in "$@"; do [ "$v" = "$b.hip" ] && flags="$flags $EXTRA"; done
   /opt/rocm/bin/hipcc $flags -c $s -o $OUT/$b.o &
