@@ -106,3 +106,21 @@ def test_maxfilter_window_reads_are_vectors():
             assert read_b128_cycles(lambda lane: (lane // W4) * SW + (lane % W4) * 4 + 4 * j) <= 8      # (the four scalar reads it replaces: 4 x 8 cycles)
             # the scalar form it replaces: one float per lane at a stride of 4 floats = 4-way
             assert read_b32_cycles(lambda lane: lane * 4 + j) == 8
+
+
+def test_implicit_gemm_row_swizzle_is_conflict_free_for_consecutive_rows():
+    """conv.hip / conv_pp.hip / conv_halo.hip: 128-byte rows, piece ^ ((row >> 1) & 7).  A fragment read takes 32 CONSECUTIVE rows (raster-order GEMM rows + a tap
+    shift); the swizzle is a bijection on the real lane groups for every starting row, which is why these kernels measure 1-4 % conflict cycles (the remainder: tap reads
+    that cross an image row, where the 32 rows are not consecutive)."""
+    for base in range(64):
+        for pc in range(8):
+            def addr(lane):
+                row = base + (lane & 31)
+                return row * 32 + (((pc ^ (2 * (lane >> 5))) ^ ((row >> 1) & 7)) << 2)
+            assert read_b128_cycles(addr) == 4
+
+    def hs_b_off(row, stage, piece):                                 # conv_halo.hip: B ring, blocks of 8 rows with the three stages of a block adjacent
+        return (((row >> 3) * 3 + stage) << 8) + ((row & 7) << 5) + ((piece ^ ((row >> 1) & 7)) << 2)
+    for stage in range(3):
+        for pc in range(8):
+            assert read_b128_cycles(lambda lane: hs_b_off(lane & 31, stage, pc ^ (2 * (lane >> 5)))) == 4
