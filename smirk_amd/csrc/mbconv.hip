@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
     // groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (MI355X_MICROARCH.md), i.e. quads 0-3 of pixel j, 4-7 of j + 1, 4-7 of j + 2, 0-3 of j + 3: with a pixel
     // stride of S * ES floats these 16 quads fall into 16 distinct 16-byte bank slots iff S * ES = 32 (mod 64) - 32 | 48 floats.  The former 36 (chosen for 16
     // CONSECUTIVE lanes) made every depthwise tap read a 2-way (stride 1) or 3-way (stride 2) conflict: 33-37 % of the kernel's LDS cycles (profiles/r03v_pmc_census_full.txt).
-    // Stride 1 takes 32 (24 -> 72 -> 24 at 56^2: 4.0 -> 2.7-3.0 ms per 1024 frames on two boxes; the 28^2 blocks within box noise).  Stride 2 stays at 36: 48 costs
-    // 7 KB more LDS per workgroup and showed no gain outside the +-25 % box-to-box spread of these kernels (4.85 ms with 48 on one box, 4.68 ms with 36 on the next:
-    // profiles/r03s_bench_full.json, r03s2_bench_full.json) - a same-box A/B is still owed.
+    // Stride 1 takes 32.  Stride 2 stays at 36 (48 costs 7 KB more LDS per workgroup).  Measured effect of either: none outside the noise - the four fused-MBConv
+    // entries of the config-4 bench table sum to 13.6-13.8 ms per 1024 frames before and after (profiles/r03z_, r03s_, r03s2_bench_full.json; the three backbones run on
+    // concurrent streams, so single entries trade +-25 % between runs).  The conflict cycles are gone from the depthwise reads; the kernel is bound by parked waves and
+    // instruction issue, not by the LDS.
     constexpr int ES = MB_ES(S), DSB = 144;               // Ds row stride (bytes: 32 ch x 4 B + 16)
     constexpr int P3 = (S == 1) ? 2 : 1;                  // project tiles per wave: (MO/32) x (Cout<=96)/32 = 6 | 3 tiles over 4 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
