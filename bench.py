@@ -88,6 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--flame-basis", choices=("random", "smooth"), default="random",
                     help="synthetic FLAME blendshape basis: 'random' = SURVEY.md 8(d) (i.i.d. directions: ~21 x 22-pixel triangle boxes); 'smooth' = low-frequency "
                          "fields like a real shape model (~4-pixel triangles) - only the rasteriser's share of the step changes")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="1 GPU only: create a world-size-1 RCCL group and really enqueue the output all-gather / gradient all-reduce of every step (what a rank of "
+                         "the N-GPU job does besides its shard); use with --global-batch 128 to measure the 8-GPU per-rank regime on one MI355X")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)   # CPU/gloo stub of the path: tests/test_distributed_cpu.py
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)       # the run that rocprofv3 wraps (no JSON line, no baseline)
@@ -389,7 +392,7 @@ class FullWorkload(Workload):
         self.hull = torch.cat([(g[:, 3:4] != 0).float().contiguous().to(dev) for g in gi])
         assert self.img.shape[0] == B
         self.given = args.given_masked
-        self.gather = OutputGatherer()
+        self.gather = OutputGatherer(force_collective=bool(getattr(args, "force_collective", False)))
         self.runner = OverlappedPipeline(self.pipe, generator_streams=args.generator_streams) if args.overlap else None
 
     def _kw(self, lo, hi):
@@ -523,6 +526,7 @@ class TrainWorkload(Workload):
         self.buckets = 0
         self.gen_step, self.enc_step = gen, enc
         self.graphs = bool(getattr(args, "train_graphs", False))
+        self.force_collective = bool(getattr(args, "force_collective", False))
         if self.graphs:                                              # forward + backward of both CNNs as four HIP graphs (smirk_amd/cycle.py)
             from smirk_amd.cycle import graph_cycle_modules
             self.gen_step, self.enc_step = graph_cycle_modules(gen, enc, torch.zeros(B, 6, 224, 224, device=dev), torch.zeros(B, 3, 224, 224, device=dev))
@@ -536,7 +540,7 @@ class TrainWorkload(Workload):
         self.rend.forward(fo['vertices'], rf['cam'])
         self.opt_e.zero_grad(set_to_none=True); self.opt_g.zero_grad(set_to_none=True)
         loss.backward()
-        self.buckets = allreduce_gradients(self.enc_params + self.gen_params)
+        self.buckets = allreduce_gradients(self.enc_params + self.gen_params, force_collective=self.force_collective)
         torch.nn.utils.clip_grad_norm_(self.gen_params, 0.1)
         self.opt_e.step(); self.opt_g.step()
         self.last = {"reconstructed_img": recon.detach(), "loss": loss.detach().reshape(1)}
@@ -647,6 +651,9 @@ def main():
         dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group(args.backend, **({"device_id": dev} if dev.type == "cuda" else {}))
+    elif args.force_collective and not args.plumbing_test:
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        dist.init_process_group(args.backend, init_method=f"tcp://127.0.0.1:{port_}", rank=0, world_size=1, device_id=dev)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or let bench.py launch itself)")
     # every rank present and reachable over the collective backend (RCCL on GPUs): an actual all-gather of the rank ids
@@ -766,7 +773,9 @@ def main():
                                                "clip + Adam), 64 frames per GPU, data-parallel"}[args.workload],
                        "frames_per_gpu_per_step": B, "global_batch": B * world, "micro_batch": min(args.micro_batch, B), "image": "224x224",
                        "parallelism": f"dp{world}", "rccl_ranks_seen": ranks_seen,
-                       "collective": ("async all_gather_into_tensor(vertices, rendered_img, reconstructed_img) per micro-batch" if world > 1 else "none (1 GPU)")
+                       "collective": ("async all_gather_into_tensor(vertices, rendered_img, reconstructed_img) per micro-batch" if world > 1 else
+                                      "async all_gather_into_tensor(...) per micro-batch through a world-size-1 RCCL group (--force-collective)"
+                                      if getattr(args, "force_collective", False) else "none (1 GPU)")
                        if args.workload == "full" or args.plumbing_test else
                        (f"bucketed all_reduce of the gradients after backward ({getattr(wl, 'buckets', 0)} buckets of <= 64 MiB)" if world > 1 else "none (1 GPU)")
                        if args.workload == "train64" else "none (outputs stay on the rank)",
@@ -788,6 +797,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
