@@ -198,6 +198,15 @@ int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* 
  * activation never reaches HBM.  Returns SMIRK_ERR_UNSUPPORTED when the shape is not served by the halo-patch kernel (H, W % 16, H >= 64). */
 int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                              const float* shift, const float* fw, const float* fb, float* out_nchw, int fcout, void* stream);
+/* The generator's FIRST encoder block in ONE launch (smirk_generator.py:52-53 `enc1 = self.encoder1(x)`, `self.pool1(enc1)`; _block :88-119 =
+ * Conv2d(3x3, pad 1, bias=False) + BatchNorm2d + ReLU, twice): x [B][H][W][8] split16 (the packed network input, in_channels <= 8) ->
+ * conv(8 -> 32) + scale1/shift1 + ReLU -> conv(32 -> 32) + scale2/shift2 + ReLU -> e1 [B][H][W][32] split16 (the skip tensor) and
+ * pooled [B][H/2][W/2][32] split16 = MaxPool2d(2, 2)(e1).  The 32-channel intermediate never reaches HBM (halo recompute, enc1_fused.hip).
+ * w1: [32][72/8][2][8] halves, w2: [32][288/8][2][8] halves (K ordered (ky,kx,c), as smirk_conv_igemm_f16x3).  H, W multiples of 16.
+ * smirk_enc1_fused_supported(cin_pad, features, H, W) -> 1 when smirk_generator_forward takes this path ($SMIRK_DISABLE_ENC1_FUSED=1: never). */
+int smirk_enc1_fused_supported(int cin_pad, int features, int H, int W);
+int smirk_enc1_fused_split16(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
+                             const float* shift2, void* e1, void* pooled, int B, int H, int W, void* stream);
 /* fp32 <-> split16 conversion of n_elems values (n_elems % 8 == 0; groups of 8 consecutive values). */
 int smirk_f32_to_split16(const float* in, void* out, size_t n_elems, void* stream);
 int smirk_split16_to_f32(const void* in, float* out, size_t n_elems, void* stream);

@@ -9,6 +9,12 @@
  *                                                     ComputeFaceBoundingBoxes, CheckPointOutsideBoundingBox
  *   csrc/utils/geometry_utils.h                     :: EdgeFunctionForward, BarycentricCoordinatesForward (kEpsilon = 1e-8)
  *   csrc/rasterize_meshes/rasterization_utils.h     :: PixToNonSquareNdc
+ * z rule (stated because releases differ): a face is skipped for EVERY pixel when its NEAREST vertex is not in front of the camera,
+ *   z_invalid = zmin < kEpsilon        ("Faces with at least one vertex behind the camera won't render correctly and should be removed
+ *                                        or clipped before calling the rasterizer" — CheckPointOutsideBoundingBox, 0.7.x, CPU and CUDA alike)
+ * i.e. a face that STRADDLES z = 0 (zmin < eps <= zmax) is dropped whole, not clipped.  Rounds 1-3 restated this as `zmax < eps` (only faces
+ * entirely behind the camera dropped; older releases); it cannot matter for SMIRK (every z is ~10 after renderer.py:144) but the restatement claims
+ * literalness, so the 0.7.x rule is implemented and pinned by tests/test_cpu_suite.py::test_raster_kat_face_straddling_z0_is_dropped_whole.
  * PARITY UNPINNED: the reference has no golden vectors for this call; correctness is defended by the analytic
  * known-answer tests in tests/test_cpu_suite.py (test_raster_kat_*, test_raster_c_matches_numpy_on_random_soup) and tests/test_raster_differential.py.
  *
@@ -53,11 +59,11 @@ void smirk_oracle_rasterize_naive(const float* face_verts, int B, int Ff, int H,
                     /* ComputeFaceAreas: EdgeFunctionForward(v0, v1, v2) */
                     const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
                     if (fabsf(face_area) <= K_EPS) continue;
-                    /* CheckPointOutsideBoundingBox, blur 0 (inclusive), z_invalid = zmax < kEpsilon */
+                    /* CheckPointOutsideBoundingBox, blur 0 (inclusive), z_invalid = zmin < kEpsilon */
                     const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
                     const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
-                    const float zmax = fmaxf(z0, fmaxf(z1, z2));
-                    if (xf > xmax || xf < xmin || yf > ymax || yf < ymin || zmax < K_EPS) continue;
+                    const float zmin = fminf(z0, fminf(z1, z2));
+                    if (xf > xmax || xf < xmin || yf > ymax || yf < ymin || zmin < K_EPS) continue;
                     /* BarycentricCoordinatesForward */
                     const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
                     const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;

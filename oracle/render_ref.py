@@ -68,7 +68,7 @@ def rasterize_numpy(face_verts, H, W):
         area = (E(x2, y2, x0, y0, x1, y1) + f32(1e-8)).astype(f32)
         xmin, xmax = np.minimum(x0, np.minimum(x1, x2)), np.maximum(x0, np.maximum(x1, x2))
         ymin, ymax = np.minimum(y0, np.minimum(y1, y2)), np.maximum(y0, np.maximum(y1, y2))
-        zmax = np.maximum(z0, np.maximum(z1, z2))
+        zmin = np.minimum(z0, np.minimum(z1, z2))                    # z_invalid = zmin < kEpsilon (raster_ref.c header)
         for yi in range(H):
             yf = f32(-1.0) + f32(f32(2.0) * f32(H - 1 - yi) + f32(1.0)) / f32(H)
             for xi in range(W):
@@ -78,7 +78,7 @@ def rasterize_numpy(face_verts, H, W):
                     w1 = (E(xf, yf, x2, y2, x0, y0) / area).astype(f32)
                     w2 = (E(xf, yf, x0, y0, x1, y1) / area).astype(f32)
                     pz = ((w0 * z0).astype(f32) + (w1 * z1).astype(f32)).astype(f32) + (w2 * z2).astype(f32)
-                ok = (np.abs(fa) > f32(1e-8)) & ~((xf > xmax) | (xf < xmin) | (yf > ymax) | (yf < ymin) | (zmax < f32(1e-8)))
+                ok = (np.abs(fa) > f32(1e-8)) & ~((xf > xmax) | (xf < xmin) | (yf > ymax) | (yf < ymin) | (zmin < f32(1e-8)))
                 ok &= ~(pz < 0) & (w0 > 0) & (w1 > 0) & (w2 > 0)
                 idx = np.nonzero(ok)[0]
                 if idx.size:

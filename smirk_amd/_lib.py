@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p = C.c_void_p
 _i = C.c_int
@@ -110,6 +110,8 @@ _SIGS = {
     "smirk_conv_igemm_f32": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_conv_igemm_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_conv3x3_tail_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "smirk_enc1_fused_supported": (_i, [_i, _i, _i, _i]),
+    "smirk_enc1_fused_split16": (_i, [_p] * 9 + [_i, _i, _i, _p]),
     "smirk_f32_to_split16": (_i, [_p, _p, _sz, _p]),
     "smirk_split16_to_f32": (_i, [_p, _p, _sz, _p]),
     "smirk_maxpool2x2_split16": (_i, [_p, _p, _i, _i, _i, _i, _p]),

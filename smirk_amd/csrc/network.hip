@@ -134,6 +134,16 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     const void* bott = nullptr;
     for (int l = 0; l < 5; ++l) {
         const int h = H >> l, wd = W >> l, c = f << l;
+        if (l == 0 && split && smirk_enc1_fused_supported(cin, f, h, wd)) {
+            // encoder1 + pool1 in one launch (enc1_fused.hip): the 32-channel full-resolution tensor between the two convolutions never reaches HBM
+            void* pl = p.rot.pick(nullptr, nullptr);
+            TRY(smirk_enc1_fused_split16(cur, w->enc[0][0].w, w->enc[0][0].scale, w->enc[0][0].shift, w->enc[0][1].w, w->enc[0][1].scale,
+                                         w->enc[0][1].shift, p.e[0], pl, B, h, wd, stream));
+            tap(0, p.e[0], act_bytes(B, h, wd, c));
+            cur = pl;
+            cin = c;
+            continue;
+        }
         void* t1 = p.rot.pick(cur, nullptr);
         TRY(conv_call(split, desc3x3(B, h, wd, cin, 0, c, false, true), cur, nullptr, w->enc[l][0], nullptr, t1, stream));
         void* t2 = l < 4 ? p.e[l] : p.rot.pick(t1, nullptr);

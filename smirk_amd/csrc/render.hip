@@ -98,11 +98,11 @@ __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f
 __device__ inline short4 face_pixel_box(const float* p, int H, int W) {
     const float xmin = fminf(p[0], fminf(p[3], p[6])), xmax = fmaxf(p[0], fmaxf(p[3], p[6]));
     const float ymin = fminf(p[1], fminf(p[4], p[7])), ymax = fmaxf(p[1], fmaxf(p[4], p[7]));
-    const float zmax = fmaxf(p[2], fmaxf(p[5], p[8]));
+    const float zmin = fminf(p[2], fminf(p[5], p[8]));                    // z_invalid = zmin < kEpsilon: a face with ANY vertex not in front of the camera is dropped whole
     const float area = edge_fn(p[0], p[1], p[3], p[4], p[6], p[7]);
     short4 box = make_short4(1, 0, 1, 0);
     const bool finite = (xmin == xmin) && (xmax == xmax) && (ymin == ymin) && (ymax == ymax);
-    if (finite && fabsf(area) > K_EPS && !(zmax < K_EPS)) {
+    if (finite && fabsf(area) > K_EPS && !(zmin < K_EPS)) {
         // pixel column xi sees ndc(W-1-xi); ndc(i) = -1 + (2i+1)/W  =>  i in [ (W(xmin+1)-1)/2 , (W(xmax+1)-1)/2 ], widened by 1
         float ilo = floorf((W * (xmin + 1.0f) - 1.0f) * 0.5f) - 1.0f, ihi = ceilf((W * (xmax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
         float jlo = floorf((H * (ymin + 1.0f) - 1.0f) * 0.5f) - 1.0f, jhi = ceilf((H * (ymax + 1.0f) - 1.0f) * 0.5f) + 1.0f;
@@ -116,7 +116,7 @@ __device__ inline short4 face_pixel_box(const float* p, int H, int W) {
 }
 
 // face record: 9 floats (x0,y0,z0,x1,y1,z1,x2,y2,z2) in pytorch3d NDC;  bbox: conservative pixel-index box (xi0,xi1,yi0,yi1),
-// empty (xi0 > xi1) for faces the reference skips wholesale (|area| <= eps, zmax < eps).
+// empty (xi0 > xi1) for faces the reference skips wholesale (|area| <= eps, zmin < eps).
 __global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H, int W, const float* __restrict__ tv,
                                                          float* __restrict__ frec, short4* __restrict__ fbox) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -144,3 +144,110 @@ def test_split16_roundtrip_is_fp32_class():
     normal = (mag >= 2.0 ** -10) & (mag < 6e4)          # hi is a normal fp16 => 22 significand bits survive
     assert (err[normal] / mag[normal]).max().item() < 2.0 ** -21
     assert err[mag < 2.0 ** -10].max().item() < 2.0 ** -31   # below that the error is bounded in absolute terms (fp16 subnormal grid / 2^11)
+
+
+# ---- enc1_fused.hip: conv(8 -> 32) + BN + ReLU -> conv(32 -> 32) + BN + ReLU -> e1 + maxpool(e1) in one launch (smirk_generator.py:52-53) ----------------
+def _enc1_case(B, H, W, seed):
+    from smirk_amd import _lib as L
+    from smirk_amd.smirk_generator import _split16
+    lib, dev = L.lib(), torch.device("cuda")
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, 8, generator=g)
+    x[..., 6:] = 0.0                                                       # the packed network input: 6 real channels, 2 zero
+    w1 = torch.randn(32, 72, generator=g) * 0.15
+    w2 = torch.randn(32, 288, generator=g) * 0.06
+    sc1, sh1 = torch.rand(32, generator=g) + .5, torch.randn(32, generator=g) * 0.3
+    sc2, sh2 = torch.rand(32, generator=g) + .5, torch.randn(32, generator=g) * 0.3
+    P = L.ptr
+    t = dict(x=x, w1=w1, w2=w2, sc1=sc1, sh1=sh1, sc2=sc2, sh2=sh2)
+    d = {k: v.to(dev) for k, v in t.items()}
+    xs = torch.empty_like(d["x"])
+    L.check(lib.smirk_f32_to_split16(P(d["x"]), P(xs), xs.numel(), L.stream_ptr()))
+    w1s, w2s = _split16(d["w1"]), _split16(d["w2"])
+    return L, lib, t, d, xs, w1s, w2s
+
+
+def _enc1_unfused(L, lib, d, xs, w1s, w2s, B, H, W):
+    P = L.ptr
+    dev = xs.device
+    def desc(cin):
+        c = L.SmirkConvDesc()
+        c.B, c.H, c.W, c.C0, c.C1, c.Cout, c.KH, c.KW, c.stride, c.pad_t, c.pad_l = B, H, W, cin, 0, 32, 3, 3, 1, 1, 1
+        c.Ho, c.Wo, c.pad_mode, c.act, c.out_mode = H, W, L.PAD_ZERO, L.ACT_RELU, L.OUT_NHWC
+        return c
+    t1, e1, pl = torch.empty(B, H, W, 32, device=dev), torch.empty(B, H, W, 32, device=dev), torch.empty(B, H // 2, W // 2, 32, device=dev)
+    L.check(lib.smirk_conv_igemm_f16x3(desc(8), P(xs), None, P(w1s), P(d["sc1"]), P(d["sh1"]), None, P(t1), L.stream_ptr()))
+    L.check(lib.smirk_conv_igemm_f16x3(desc(32), P(t1), None, P(w2s), P(d["sc2"]), P(d["sh2"]), None, P(e1), L.stream_ptr()))
+    L.check(lib.smirk_maxpool2x2_split16(P(e1), P(pl), B, H, W, 32, L.stream_ptr()))
+    return e1, pl
+
+
+def _enc1_fused(L, lib, d, xs, w1s, w2s, B, H, W):
+    P = L.ptr
+    dev = xs.device
+    e1 = torch.full((B, H, W, 32), float("nan"), device=dev)
+    pl = torch.full((B, H // 2, W // 2, 32), float("nan"), device=dev)
+    L.check(lib.smirk_enc1_fused_split16(P(xs), P(w1s), P(d["sc1"]), P(d["sh1"]), P(w2s), P(d["sc2"]), P(d["sh2"]), P(e1), P(pl), B, H, W, L.stream_ptr()))
+    torch.cuda.synchronize()
+    return e1, pl
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(1, 16, 16, 0), (2, 32, 48, 1), (3, 224, 224, 2), (1, 64, 16, 3), (5, 16, 32, 4), (7, 112, 224, 5)])
+def test_enc1_fused_block_matches_fp64_and_the_unfused_kernels(B, H, W, seed):
+    """one patch (every halo pixel outside the image), ragged patch counts (idle groups / workgroups), the benchmark geometry: the fused block is within the
+    conv tolerance of torch fp64, within fp32 rounding of the three launches it replaces, and its pooled output is EXACTLY MaxPool2d(2,2) of its own e1"""
+    from smirk_amd.smirk_generator import split16_to_float
+    L, lib, t, d, xs, w1s, w2s = _enc1_case(B, H, W, seed)
+    e1, pl = _enc1_fused(L, lib, d, xs, w1s, w2s, B, H, W)
+    u1, upl = _enc1_unfused(L, lib, d, xs, w1s, w2s, B, H, W)
+    torch.cuda.synchronize()
+    xq = split16_to_float(xs).cpu().double().permute(0, 3, 1, 2)             # the split16 image of x is what both paths convolve
+    w1q = split16_to_float(w1s.view(1, 1, 32, 72)).view(32, 72).cpu().double()
+    w2q = split16_to_float(w2s.view(1, 1, 32, 288)).view(32, 288).cpu().double()
+    bn = lambda y, sc, sh: F.relu(y * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    y1 = bn(F.conv2d(xq, w1q.reshape(32, 3, 3, 8).permute(0, 3, 1, 2), padding=1), t["sc1"], t["sh1"])
+    y2 = bn(F.conv2d(y1, w2q.reshape(32, 3, 3, 32).permute(0, 3, 1, 2), padding=1), t["sc2"], t["sh2"])
+    ref_e1, ref_pl = y2.permute(0, 2, 3, 1), F.max_pool2d(y2, 2, 2).permute(0, 2, 3, 1)
+    f_e1, f_pl = split16_to_float(e1).cpu().double(), split16_to_float(pl).cpu().double()
+    assert torch.isfinite(f_e1).all() and torch.isfinite(f_pl).all()         # every pixel of both outputs was written (they were NaN-filled)
+    def where(err):                                                          # which (row, column, channel) sets are wrong: names the broken index map at a glance
+        bad = (err >= TOL).nonzero()
+        return {n: sorted(set(bad[:, k].tolist()))[:40] for k, n in enumerate(("b", "y", "x", "c"))}
+    e_e1, e_pl = (f_e1 - ref_e1).abs(), (f_pl - ref_pl).abs()
+    assert e_e1.max().item() < TOL, where(e_e1)
+    assert e_pl.max().item() < TOL, where(e_pl)
+    # against the kernels it replaces: same arithmetic class, different k packing of conv1 (two taps per MFMA step) => fp32 rounding only
+    assert (f_e1 - split16_to_float(u1).cpu().double()).abs().max().item() < 2e-5
+    # pooled == max-pool of its own e1, bit for bit (max commutes with the monotone split)
+    own = torch.empty_like(pl)
+    L.check(lib.smirk_maxpool2x2_split16(L.ptr(e1), L.ptr(own), B, H, W, 32, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(own, pl)
+
+
+def test_enc1_fused_is_batch_invariant_and_deterministic():
+    """a frame's result does not depend on the batch it travels in (patch -> workgroup assignment changes with B) nor on the run"""
+    L, lib, t, d, xs, w1s, w2s = _enc1_case(6, 64, 64, 11)
+    e1, pl = _enc1_fused(L, lib, d, xs, w1s, w2s, 6, 64, 64)
+    e1b, plb = _enc1_fused(L, lib, d, xs, w1s, w2s, 6, 64, 64)
+    assert torch.equal(e1, e1b) and torch.equal(pl, plb)
+    for b in (0, 5):
+        s1, sp = _enc1_fused(L, lib, d, xs[b:b + 1].contiguous(), w1s, w2s, 1, 64, 64)
+        assert torch.equal(s1[0], e1[b]) and torch.equal(sp[0], pl[b])
+
+
+def test_generator_forward_with_and_without_the_fused_first_block(monkeypatch):
+    """smirk_generator_forward takes enc1_fused.hip by default; SMIRK_DISABLE_ENC1_FUSED=1 restores the three launches — both within the generator tolerance of each other"""
+    from oracle import generator_ref as G
+    from smirk_amd import SmirkGenerator, synth
+    gsd = G.synth_state_dict()
+    gen = SmirkGenerator(6, 3, 32, 5); gen.load_state_dict(gsd); gen = gen.cuda().eval()
+    x = synth.synth_generator_input(2, seed=3).cuda()
+    with torch.no_grad():
+        a = gen(x)
+        monkeypatch.setenv("SMIRK_DISABLE_ENC1_FUSED", "1")
+        b = gen(x)
+    torch.cuda.synchronize()
+    assert (a - b).abs().max().item() < 2e-5
+    y = G.forward(gsd, x.cpu())
+    assert (a.cpu() - y).abs().max().item() < 2e-5

@@ -125,6 +125,41 @@ def test_raster_kat_z_order_tie_and_shared_edge():
     assert (p2f == -1).all()
 
 
+def test_raster_kat_face_straddling_z0_is_dropped_whole():
+    """z rule of oracle/raster_ref.c (pytorch3d 0.7.x CheckPointOutsideBoundingBox): z_invalid = zmin < kEpsilon — a face with ANY vertex at or behind
+    the camera plane is skipped for every pixel (not clipped), even where its interpolated depth is positive; a face with zmin just above eps renders."""
+    S = 8
+    full = lambda z0, z1, z2: [[-1, -1, z0], [3, -1, z1], [-1, 3, z2]]                  # covers the whole image
+    # (1) straddles z = 0: zmin = -1 < eps <= zmax = 5  -> dropped everywhere, although pz > 0 on most pixels
+    for fn in (R.rasterize_naive, R.rasterize_numpy):
+        p2f, zb, bary = fn(_tri(full(-1.0, 5.0, 5.0)), S, S)
+        assert (p2f == -1).all() and (zb == -1).all() and (bary == -1).all()
+    # (2) zmin < eps < zmax with zmin POSITIVE but below kEpsilon (5e-9): still dropped
+    for fn in (R.rasterize_naive, R.rasterize_numpy):
+        assert (fn(_tri(full(5e-9, 2.0, 2.0)), S, S)[0] == -1).all()
+    # (3) zmin == 2e-8 > eps: rendered on every pixel, depth = the interpolated z
+    for fn in (R.rasterize_naive, R.rasterize_numpy):
+        p2f, zb, _ = fn(_tri(full(2e-8, 2.0, 2.0)), S, S)
+        assert (p2f == 0).all() and (zb > 0).all()
+    # (4) a dropped straddling face does not occlude the valid face behind it
+    p2f, zb, _ = R.rasterize_naive(_tri(full(-1.0, 5.0, 5.0), full(3.0, 3.0, 3.0)), S, S)
+    assert (p2f == 1).all() and np.allclose(zb, 3.0)
+    # (5) entirely behind the camera: dropped (the rule the older zmax form also implemented)
+    assert (R.rasterize_naive(_tri(full(-2.0, -2.0, -2.0)), S, S)[0] == -1).all()
+
+
+def test_raster_c_matches_numpy_on_random_soup_with_faces_behind_the_camera():
+    rng = np.random.default_rng(5)
+    fv = rng.uniform(-1.2, 1.2, (2, 40, 3, 3)).astype(np.float32)
+    fv[..., 2] = rng.uniform(-1.0, 3, (2, 40, 3))                                        # about a third of the faces have a vertex behind z = 0
+    a, b = R.rasterize_naive(fv, 16, 16), R.rasterize_numpy(fv, 16, 16)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    zmin = fv[..., 2].min(-1)
+    drawn = np.unique(a[0][0][a[0][0] >= 0])
+    assert (zmin[0][drawn] >= 1e-8).all() and (zmin < 1e-8).any()
+
+
 def test_raster_c_matches_numpy_on_random_soup():
     rng = np.random.default_rng(0)
     fv = rng.uniform(-1.2, 1.2, (2, 40, 3, 3)).astype(np.float32)

@@ -82,6 +82,33 @@ def test_render_edge_cases(rend, sandbox):
     assert np.abs(out["rendered_img"] - ref["rendered_img"]).max() < PIX_TOL
 
 
+def test_render_faces_straddling_the_camera_plane(rend, sandbox):
+    """z rule (oracle/raster_ref.c header; pytorch3d 0.7.x): a face with ANY vertex at z < kEpsilon is dropped whole.  The mesh is pushed along z until the
+    plane z = 0 (after renderer.py:144's +10) cuts through it: HIP and oracle must drop exactly the same faces — bit-exact indices, barycentrics, depth."""
+    fr = FlameRef(sandbox)
+    p = A.synth_flame_params(3, seed=11)
+    p["shape_params"] *= 0.4
+    verts = fr.forward(p)["vertices"]
+    cam = A.synth_cam(3, seed=11)
+    rr = RendererRef(sandbox)
+    base = rr.forward(verts, cam)
+    cov0 = (base["_aux"]["pix_to_face"] >= 0).mean()
+    hit = False
+    for sign in (1.0, -1.0):
+        v = verts.copy()
+        v[..., 2] += sign * 10.0 / cam[:, None, 0]                                  # z' = +-s z + 10 crosses 0 inside the head for one of the two signs
+        ref = rr.forward(v, cam)
+        out, aux = _gpu(rend, v, cam)
+        p2f = ref["_aux"]["pix_to_face"].astype(np.int64)
+        packed = np.where(p2f >= 0, p2f + (np.arange(3, dtype=np.int64) * 3408)[:, None, None], -1)
+        assert np.array_equal(aux["pix_to_face"], packed)
+        assert np.array_equal(aux["bary"], ref["_aux"]["bary"]) and np.array_equal(aux["zbuf"], ref["_aux"]["zbuf"])
+        assert np.abs(out["rendered_img"] - ref["rendered_img"]).max() < PIX_TOL
+        cov = (packed >= 0).mean()
+        hit = hit or (0.0 < cov < 0.9 * cov0)                                       # part of the mesh dropped, part still drawn
+    assert hit
+
+
 def test_render_batch_permutation(rend, sandbox):
     p = A.synth_flame_params(5, seed=4)
     verts = FlameRef(sandbox).forward(p)["vertices"]
