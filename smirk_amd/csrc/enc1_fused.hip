@@ -19,7 +19,7 @@
 //   * One 512-thread workgroup per CU = TWO 4-wave groups, each walking its own patches through conv1 | epilogue 1 | conv2 | epilogue 2, ONE PHASE APART
 //     and separated by the workgroup barrier: while one group's waves issue MFMAs the other group's waves on the same SIMDs run an epilogue (VALU / LDS /
 //     stores).  The groups share the weights (W2 36 KB + W1 10 KB) — two independent workgroups per CU would not fit (2 x 90 KB).
-// LDS: W2 36,864 + W1 10,240 + coefficients / dump row 640 + 2 x (input halo 14,336 + intermediate 41,472) = 159,360 B.
+// LDS: W2 36,864 + W1 10,240 + coefficients 512 + 2 x (input halo 14,336 + intermediate 41,472) = 159,232 B.
 //
 // Bound: per patch 597 MFMAs (conv1 165 on 11 row tiles, conv2 432) = 4.8 k matrix-pipe cycles per CU against 9.9 GB / 1024 frames of HBM traffic
 // (~2 ms at 5 TB/s): MFMA / VALU co-bound, HBM close behind.  Algorithmic flop = 2 * B*H*W * 32 * (72 + 288).
@@ -32,6 +32,12 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
+#ifndef E1_PHASE_OFFSET
+#define E1_PHASE_OFFSET 1                           // 1: group 1 runs one phase behind group 0; 0: both groups in the same phase
+#endif
+#ifndef E1_DIRECT_STORES
+#define E1_DIRECT_STORES 0                         // epilogue 2: 1 = every lane stores its own 8-byte pieces, 0 = tiles staged through LDS and stored as 1 KiB runs
+#endif
 #define E1_PT 16                                  // output patch edge
 #define E1_IH (E1_PT + 2)                         // intermediate (conv1 output) halo edge: 18
 #define E1_XH (E1_PT + 4)                         // input halo edge: 20
@@ -40,7 +46,7 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 #define E1_XSLOTS 448                             // 7 DMA instructions of 64 pixels per half plane
 #define E1_W2_BYTES (9 * 32 * 128)                // [tap][n][32 dwords], XOR piece swizzle
 #define E1_W1_BYTES (5 * 2 * 2 * 32 * 16)         // [k-step][hi|lo][lane half][n] 16-byte pieces
-#define E1_COEF_BYTES 640                         // scale1, shift1, scale2, shift2 (32 floats each) + a 128-byte dump row (stores of lanes that own no pixel)
+#define E1_COEF_BYTES 512                         // scale1, shift1, scale2, shift2 (32 floats each)
 #define E1_XIN_BYTES (2 * E1_XSLOTS * 16)         // planar: hi pieces of the 400 (+48) halo pixels, then their lo pieces
 #define E1_INT_BYTES (E1_IPIX * 128)              // [pixel][4 groups x (8 hi | 8 lo)], piece swizzle by halo column
 #define E1_GROUP_BYTES (E1_XIN_BYTES + E1_INT_BYTES)
@@ -52,13 +58,13 @@ struct Enc1Args {
     float *e1, *pool;
     int B, H, W;
     int npatch;            // B * (H/16) * (W/16)
-    long long* dbg;        // -DSMIRK_DEBUG_HOOKS variant builds only: phase time stamps [2 workgroups][2 groups][E1_DBG_IT][10] (tools/enc1_timeline.py)
+    long long* dbg;        // -DSMIRK_DEBUG_HOOKS variant builds only: phase time stamps [2 workgroups][2 groups][E1_DBG_IT][16] (tools/enc1_timeline.py)
 };
 #ifdef SMIRK_DEBUG_HOOKS
 #define E1_DBG_IT 24
 #define E1_STAMP(k)                                                                                                   \
     do {                                                                                                              \
-        if (dbg_p && it < E1_DBG_IT) dbg_p[it * 10 + (k)] = (long long)__builtin_readcyclecounter();                   \
+        if (dbg_p && it < E1_DBG_IT) dbg_p[it * 16 + (k)] = (long long)__builtin_readcyclecounter();                   \
     } while (0)
 #else
 #define E1_STAMP(k) do {} while (0)
@@ -237,8 +243,7 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
     const unsigned stg0 = lds_i + (unsigned)wave * E1_STAGE_BYTES;
     const unsigned e2_w = stg0 + (unsigned)fr * 128u + (unsigned)(((fr >> 1) & 7) << 4) + (unsigned)hb * 8u;
     const bool pool_lane = ry == 1 && (rx & 1) == 0;                  // e1_pool4's result is valid in the odd 16-lane rows
-    const unsigned e2_pw = pool_lane ? stg0 + 32u * 128u + (unsigned)(rx >> 1) * 128u + (unsigned)(((rx >> 2) & 7) << 4) + (unsigned)hb * 8u
-                                     : (unsigned)(E1_W2_BYTES + E1_W1_BYTES + 512) + (unsigned)hb * 8u;
+    const unsigned e2_pw = stg0 + 32u * 128u + (unsigned)(rx >> 1) * 128u + (unsigned)(((rx >> 2) & 7) << 4) + (unsigned)hb * 8u;
     const unsigned e2_r = stg0 + (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ ((lane >> 4) & 7)) << 4);        // read-back: row q*8 + lane/8, piece lane%8
 
     // ---- prologue: first halo of each group in flight, weights landed -----------------------------------------------------------------------------
@@ -247,11 +252,13 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
     if (np_group > 0) issue_xin(gidx);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if E1_PHASE_OFFSET
     if (group == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one phase behind group 0
+#endif
 
 #ifdef SMIRK_DEBUG_HOOKS
     const int dbg_blk = blockIdx.x == 0 ? 0 : blockIdx.x == 97 ? 1 : -1;
-    long long* const dbg_p = (a.dbg && dbg_blk >= 0 && wave == 0 && lane == 0) ? a.dbg + (size_t)(dbg_blk * 2 + group) * E1_DBG_IT * 10 : nullptr;
+    long long* const dbg_p = (a.dbg && dbg_blk >= 0 && wave == 0 && lane == 0) ? a.dbg + (size_t)(dbg_blk * 2 + group) * E1_DBG_IT * 16 : nullptr;
 #endif
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < np_max; ++it) {
@@ -300,9 +307,9 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
         __builtin_amdgcn_s_barrier();                                // every wave of the group has read XIN: it may be refilled
         E1_STAMP(2);
 
-        // ================= phase 1: next halo requested; conv1 epilogue: BN + ReLU, zero outside the image, split16 -> INT =================================
+        // ================= phase 1: conv1 epilogue: BN + ReLU, zero outside the image, split16 -> INT =================================
         if (act) {
-            if (it + 1 < np_group) issue_xin(p + gstride);
+            E1_STAMP(10);
             f32x4 sc[4], sh[4];                                       // this lane's 16 channels (4 per group j): one LDS round trip per phase
 #pragma unroll
             for (int j = 0; j < 4; ++j) { sc[j] = *(const f32x4*)(coef + 0 + j * 8 + hb * 4); sh[j] = *(const f32x4*)(coef + 32 + j * 8 + hb * 4); }
@@ -315,9 +322,8 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                     const int hy = (mc * 3641) >> 16, hx = mc - hy * E1_IH;
                     const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
                     const bool inimg = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                    // rows past the halo (tile 10 holds 4 pixels) store into the dump row: no branch around the stores
-                    const unsigned dst = m < E1_IPIX ? lds_i + (unsigned)mc * 128u + (unsigned)hb * 8u + (unsigned)(((hx >> 1) & 7) << 4)
-                                                      : (unsigned)(E1_W2_BYTES + E1_W1_BYTES + 512) + (unsigned)hb * 8u;
+                    const unsigned dst = lds_i + (unsigned)mc * 128u + (unsigned)hb * 8u + (unsigned)(((hx >> 1) & 7) << 4);
+                    const bool own = m < E1_IPIX;                     // rows past the halo (tile 10 holds 4 pixels) store nothing
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {                  // 8 values (channel groups 2 hf, 2 hf + 1) at a time: enough independent work, half the temporaries
                         float y[8];
@@ -333,15 +339,18 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                         E1_FENCE();
                         unsigned hi[4], lo[4];
                         e1_split8(y, hi, lo);
+                        if (own) {                                    // (a dump row for the other lanes serialises: same-address LDS writes are bank conflicts)
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = hf * 2 + jj;
-                            const uint2v vh = {hi[2 * jj], hi[2 * jj + 1]}, vl = {lo[2 * jj], lo[2 * jj + 1]};
-                            *(uint2v*)L(dst ^ (unsigned)((2 * j) << 4)) = vh;
-                            *(uint2v*)L(dst ^ (unsigned)((2 * j + 1) << 4)) = vl;
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const int j = hf * 2 + jj;
+                                const uint2v vh = {hi[2 * jj], hi[2 * jj + 1]}, vl = {lo[2 * jj], lo[2 * jj + 1]};
+                                *(uint2v*)L(dst ^ (unsigned)((2 * j) << 4)) = vh;
+                                *(uint2v*)L(dst ^ (unsigned)((2 * j + 1) << 4)) = vl;
+                            }
                         }
                         E1_FENCE();
                     }
+                    E1_STAMP(11 + t);
                 }
             }
         }
@@ -353,6 +362,9 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
         // ================= phase 2: conv2 (32 -> 32) on the 16 x 16 patch from INT; wave w owns output rows 4 w .. 4 w + 3 =================================
         f32x16 d0[2], d1[2];
         if (act) {
+            // the next patch's input halo is requested here, under the MFMAs (XIN is free since the barrier that ended phase 0); issued from the epilogue
+            // phase it cost that phase ~1.1 k cycles (address arithmetic + the LDS-DMA instructions' own issue time) and the epilogues set the period
+            if (it + 1 < np_group) issue_xin(p + gstride);
             unsigned a2[3] = {c2_a[0], c2_a[1], c2_a[2]}, b2 = c2_b;
             asm volatile("" : "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(b2));
             half8 bh[2], bl[2], ah[2][2], al[2][2];
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the next patch's halo (requested in phase 1) has landed before anyone passes this barrier; no store of this wave is outstanding here
+        // the next patch's halo (requested at the start of this phase) has landed before anyone passes this barrier; no store of this wave is outstanding here
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         E1_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -433,18 +445,50 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                     unsigned hi[4], lo[4], phi[4], plo[4];
                     e1_split8(y, hi, lo);
                     e1_split8(pz, phi, plo);
+#if E1_DIRECT_STORES
+                    {   // each lane stores its own 8-byte pieces: a pixel's 128-byte line is completed by 8 instructions x 2 lane halves and merged in L2
+                        float* const o = a.e1 + (((size_t)b * H + oy0 + 4 * wave + 2 * i + ry) * W + ox0 + rx) * 32 + hb * 2;
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = hf * 2 + jj;
+                            const uint2v vh = {hi[2 * jj], hi[2 * jj + 1]}, vl = {lo[2 * jj], lo[2 * jj + 1]};
+                            *(uint2v*)(o + j * 8) = vh;
+                            *(uint2v*)(o + j * 8 + 4) = vl;
+                        }
+                        if (pool_lane) {
+                            float* const po = a.pool + (((size_t)b * (H >> 1) + ((oy0 + 4 * wave + 2 * i) >> 1)) * (W >> 1) + ((ox0 + rx) >> 1)) * 32 + hb * 2;
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const int j = hf * 2 + jj;
+                                const uint2v ph = {phi[2 * jj], phi[2 * jj + 1]}, pl = {plo[2 * jj], plo[2 * jj + 1]};
+                                *(uint2v*)(po + j * 8) = ph;
+                                *(uint2v*)(po + j * 8 + 4) = pl;
+                            }
+                        }
+                    }
+                    E1_FENCE();
+                }
+                if (i == 0) { E1_STAMP(14); E1_STAMP(15); }
+#else
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = hf * 2 + jj;
                         const uint2v vh = {hi[2 * jj], hi[2 * jj + 1]}, vl = {lo[2 * jj], lo[2 * jj + 1]};
                         *(uint2v*)L(w3 ^ (unsigned)((2 * j) << 4)) = vh;
                         *(uint2v*)L(w3 ^ (unsigned)((2 * j + 1) << 4)) = vl;
-                        const uint2v ph = {phi[2 * jj], phi[2 * jj + 1]}, pl = {plo[2 * jj], plo[2 * jj + 1]};
-                        *(uint2v*)L(pw3 ^ (unsigned)((2 * j) << 4)) = ph;           // lanes that do not own a pooled pixel point at the dump row
-                        *(uint2v*)L(pw3 ^ (unsigned)((2 * j + 1) << 4)) = pl;
+                    }
+                    if (pool_lane) {                                  // 16 of the 64 lanes own a pooled pixel (exec mask; a shared dump address would serialise)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = hf * 2 + jj;
+                            const uint2v ph = {phi[2 * jj], phi[2 * jj + 1]}, pl = {plo[2 * jj], plo[2 * jj + 1]};
+                            *(uint2v*)L(pw3 ^ (unsigned)((2 * j) << 4)) = ph;
+                            *(uint2v*)L(pw3 ^ (unsigned)((2 * j + 1) << 4)) = pl;
+                        }
                     }
                     E1_FENCE();
                 }
+                if (i == 0) E1_STAMP(14);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // per-wave staging: LDS operations of one wave execute in order
                 const int oy = oy0 + 4 * wave + 2 * i;
                 // 64 lanes x 16 B = 8 consecutive pixels = 1 KiB per instruction: rows q*8 .. q*8+7 of the tile are pixels (q >> 1, (q & 1) * 8 ..) of the 2 x 16 tile;
@@ -461,6 +505,8 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                     *(uint4v*)o = val;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staging area is rewritten by the next tile
+                if (i == 0) E1_STAMP(15);
+#endif
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -468,7 +514,9 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
         __builtin_amdgcn_s_barrier();                                // staging reads done: INT may be written by the next patch's phase 1
         E1_STAMP(9);
     }
+#if E1_PHASE_OFFSET
     if (group == 0) __builtin_amdgcn_s_barrier();                    // both groups have executed the same number of barriers
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------------------
