@@ -117,7 +117,8 @@ def build_modules(sandbox, device, want=("enc", "flame", "rend", "gen")):
     """Random-init weights of the reference architecture (no checkpoint is obtainable offline), He-initialised so that activations stay
     O(1) through all 30+ layers (nn.Conv2d's default init shrinks them by ~2.4x per layer); every output is checked finite after warm-up."""
     import torch
-    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, synth
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator
+    import synthdata as synth
     synth.write_sandbox(sandbox, basis=os.environ.get("SMIRK_BENCH_FLAME_BASIS", "random"))
     cwd = os.getcwd()
     os.chdir(sandbox)
@@ -185,7 +186,7 @@ def cpu_baseline(sandbox, workload, n_faces, threads=None, all_cores=False):
     from oracle import generator_ref as G, mobilenet_ref as M
     from oracle.flame_ref import FlameRef
     from oracle.render_ref import RendererRef
-    from smirk_amd import synth
+    import synthdata as synth
     nthr = int(threads)
     torch.set_num_threads(nthr)
     os.environ["OMP_NUM_THREADS"] = str(nthr)
@@ -369,7 +370,8 @@ class FullWorkload(Workload):
 
     def __init__(self, args, dev, rank, world, sandbox):
         import torch
-        from smirk_amd import masking as MK, synth
+        from smirk_amd import masking as MK
+        import synthdata as synth
         from smirk_amd.pipeline import OutputGatherer, OverlappedPipeline, SmirkPipeline
         enc, flame, rend, gen = build_modules(sandbox, dev)
         self.gen = gen
@@ -447,7 +449,7 @@ class InferWorkload(Workload):
 
     def __init__(self, args, dev, rank, world, sandbox):
         import torch
-        from smirk_amd import synth
+        import synthdata as synth
         from smirk_amd.pipeline import SmirkPipeline
         enc, flame, rend, _ = build_modules(sandbox, dev, want=("enc", "flame", "rend"))
         self.pipe = SmirkPipeline(enc, flame, rend, None)
@@ -468,7 +470,7 @@ class FlameWorkload(Workload):
 
     def __init__(self, args, dev, rank, world, sandbox):
         import torch
-        from smirk_amd import synth
+        import synthdata as synth
         _, flame, _, _ = build_modules(sandbox, dev, want=("flame",))
         self.flame = flame
         self.B = per_rank_batch(args, world)
@@ -492,7 +494,8 @@ class TrainWorkload(Workload):
 
     def __init__(self, args, dev, rank, world, sandbox):
         import torch
-        from smirk_amd import masking as MK, synth
+        from smirk_amd import masking as MK
+        import synthdata as synth
         enc, flame, rend, gen = build_modules(sandbox, dev)
         self.enc, self.flame, self.rend, self.gen, self.MK = enc, flame, rend, gen, MK
         cwd = os.getcwd(); os.chdir(sandbox)

@@ -269,7 +269,7 @@ int smirk_sample_faces(const float* weights, int B, int F, int num, uint64_t see
 /* npoints = (.5 * (1 + p) * S).long(), x and y clamped to [0, S-1] (masking.py:172-175): points[B][L][3] -> out[B][L][3] int64. */
 int smirk_points_to_pixels(const float* points, int B, int L, int image_size, int64_t* out, void* stream);
 /* out = max_pool2d(in, 2r+1, stride 1, padding r) on [B][1][H][W] as two separable passes (tmp = scratch of the same size).
- * complement bit 0: pool (1 - in) instead of in; bit 1: return 1 - result.  3 => 1 - maxpool(1 - in) (masking.py:78), 2 => 1 - maxpool(in) (:96). */
+ * complement bit 0: pool (1 - in) instead of in; bit 1: return 1 - result.  3 => 1 - maxpool(1 - in) (masking.py:78), 2 => 1 - maxpool(in) (:96).  `tmp` must alias neither `in` nor `out` (SMIRK_ERR_BAD_ARG); in == out is allowed (it takes the two-pass kernels through tmp). */
 int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int W, int radius, int complement, void* stream);
 int smirk_bernoulli_field(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 /* masking.py:84-101: out = extra' > 0 ? extra' : img * mask * (1 - rendered_mask), extra' = extra_points * noise * keep.

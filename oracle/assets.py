@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-Reference-side asset helpers.  The seeded synthetic assets / inputs themselves live in smirk_amd/synth.py (INPUT generation is
+Reference-side asset helpers.  The seeded synthetic assets / inputs themselves live in synthdata.py (INPUT generation is
 shared so the GPU path and this oracle see identical bits); this module adds the OBJ reader used by the pytorch3d stub and the
 script that packs the reference's public assets into tests/golden/assets_bundle.npz.
 
@@ -19,7 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
-from smirk_amd.synth import (BUNDLE, F, V, load_bundle, synth_cam, synth_flame_model, synth_flame_params,  # noqa: F401,E402
+from synthdata import (BUNDLE, F, V, load_bundle, synth_cam, synth_flame_model, synth_flame_params,  # noqa: F401,E402
                              synth_generator_input, synth_images, write_obj, write_sandbox)
 
 

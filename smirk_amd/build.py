@@ -16,8 +16,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsmirk_hip.so")
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps hipcc from fusing pairs of fp32 operations into packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 /
-# v_pk_add_f32).  Measured on the MI355X boxes of this pool (DESIGN.md §6 "packed-FP32 under co-residency"; tools/overlap_diff5.py,
-# tools/overlap_diff6.py): a wave executing v_pk_*_f32 returns WRONG results in some 16-lane groups while a wave of ANOTHER kernel that issues
+# v_pk_add_f32).  Measured on the MI355X boxes of this pool (DESIGN.md §6 "packed-FP32 under co-residency"; tools/overlap_diff.py and its siblings in the git history,
+# round 3): a wave executing v_pk_*_f32 returns WRONG results in some 16-lane groups while a wave of ANOTHER kernel that issues
 # fp16 MFMAs + ds_read_b128 (the generator's implicit-GEMM kernels, launched from a second stream) is resident on the same CU — FLAME
 # vertices and rendered pixels were corrupted in 10/10 concurrent trials with the packed instructions and in 0/10 without them; waits,
 # barriers, LDS contents and out-of-bounds writes were all ruled out first.  The two-stream pipeline needs that co-residency, so the packed

@@ -18,6 +18,20 @@ __device__ __forceinline__ void smirk_split1(float v, _Float16& hi, _Float16& lo
     lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
+// Two values per conversion instruction (gfx950 v_cvt_pk_f16_f32; same round-to-nearest-even as v_cvt_f16_f32, so the SAME (hi, lo) pairs as smirk_split1):
+// 8 VALU per pair instead of 12.  hi / lo are returned packed (a in the low half).  Scalar arithmetic on purpose: no packed-FP32 instructions (build.py).
+typedef _Float16 smirk_half2 __attribute__((ext_vector_type(2)));
+typedef float smirk_float2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void smirk_split2(float a, float b, smirk_half2& hi, smirk_half2& lo) {
+    asm("" : "+v"(a));
+    asm("" : "+v"(b));
+    const smirk_float2 v = {a, b};
+    hi = __builtin_convertvector(v, smirk_half2);
+    const float da = (a - (float)hi.x) * 2048.0f, db = (b - (float)hi.y) * 2048.0f;
+    const smirk_float2 d = {da, db};
+    lo = __builtin_convertvector(d, smirk_half2);
+}
+
 #define SMIRK_WAVE 64
 
 static inline size_t smirk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

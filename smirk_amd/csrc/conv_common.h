@@ -36,10 +36,10 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // 8 fp32 values -> split-fp16 group: out_hi = fp16(v), out_lo = fp16((v - hi) * 2^11)
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        _Float16 h, l;
-        smirk_split1(v[q], h, l);
-        hi[q] = h; lo[q] = l;
+    for (int q = 0; q < 8; q += 2) {
+        smirk_half2 h, l;
+        smirk_split2(v[q], v[q + 1], h, l);
+        hi[q] = h.x; hi[q + 1] = h.y; lo[q] = l.x; lo[q + 1] = l.y;
     }
 }
 __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }

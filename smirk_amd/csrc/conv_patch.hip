@@ -95,10 +95,10 @@ __device__ __forceinline__ void frag_ready(const half8& a0, const half8& a1, con
 
 __device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        _Float16 h, l;
-        smirk_split1(v[q], h, l);
-        hi[q] = h; lo[q] = l;
+    for (int q = 0; q < 8; q += 2) {
+        smirk_half2 h, l;
+        smirk_split2(v[q], v[q + 1], h, l);
+        hi[q] = h.x; hi[q + 1] = h.y; lo[q] = l.x; lo[q + 1] = l.y;
     }
 }
 
@@ -706,6 +706,7 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    // (round 4: two 4-wave groups sharing the weights on 16 x 16 patches, <1,1,16,2> with the LDS-counter group barrier: dec1a 7.38 -> 10.72 ms — removed again)
     // three-stage ring variants (Cout = 32), opt-in for A/B: SMIRK_PATCH_RING=8 (16 x 8 patches) / =16 (16 x 16 patches, single-chunk layers only).
     // Measured (B = 128, 224^2, 32 -> 32): ring of 16 x 8 patches 0.84 ms vs 0.54 ms for two single-stage workgroups per CU — a lone 4-wave
     // workgroup with ONE M tile per wave has two accumulator chains per wave and nothing else on its SIMD: MFMA latency, not DMA latency, decides.

@@ -333,19 +333,24 @@ extern "C" int smirk_points_to_pixels(const float* points, int B, int L, int ima
     return smirk_launch_status();
 }
 
+// returns false when the > 64 KB dynamic-LDS opt-in failed on this device (the caller then takes the two-pass kernels instead of a launch that would fail)
 template <int R>
-static void launch_maxpool_lds(const float* in, float* out, int B, int H, int W, int complement, hipStream_t st) {
+static bool launch_maxpool_lds(const float* in, float* out, int B, int H, int W, int complement, hipStream_t st) {
     const size_t lds = (size_t)(MP_ROWS + 2 * R) * ((size_t)mp_row_stride(W, R) + W) * sizeof(float);
     static bool attr_done[64] = {};                    // per device: the attribute is per-device state (one process may drive several GPUs)
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)maxpool_sq_lds_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)maxpool_sq_lds_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;                              // not marked done: retried (and reported through the fallback) on the next call
+        }
         attr_done[dev] = true;
     }
     const int tiles = (H + MP_ROWS - 1) / MP_ROWS;
     smirk_prof_next(nullptr, 0.0, 2.0 * B * H * W * sizeof(float));
     SMIRK_LAUNCH(maxpool_sq_lds_kernel<R>, dim3((unsigned)(B * tiles)), dim3(512), lds, st, in, out, H, W, complement & 1, (complement >> 1) & 1);
+    return true;
 }
 
 extern "C" int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, int H, int W, int radius, int complement, void* stream) {
@@ -353,9 +358,12 @@ extern "C" int smirk_maxpool_sq(const float* in, float* tmp, float* out, int B, 
     const size_t n = (size_t)B * H * W;
     // the fused LDS form covers the radii the reference uses (masking.py:78 -> 10, :96 -> 5) at widths whose staged rows fit 160 KB of LDS
     const size_t staged = (size_t)(MP_ROWS + 2 * radius) * ((size_t)W + mp_row_stride(W, radius)) * sizeof(float);
-    const bool lds_ok = staged <= 160 * 1024 && (size_t)B * ((H + MP_ROWS - 1) / MP_ROWS) < 0x7fffffffull;
-    if (lds_ok && radius == 10) { launch_maxpool_lds<10>(in, out, B, H, W, complement, (hipStream_t)stream); return smirk_launch_status(); }
-    if (lds_ok && radius == 5) { launch_maxpool_lds<5>(in, out, B, H, W, complement, (hipStream_t)stream); return smirk_launch_status(); }
+    // The fused form reads rows [y0 - R, y0 + 32 + R) of `in` while other workgroups write `out`: in == out (alias-safe in the two-pass form, which goes
+    // through tmp) would race, so an aliased call keeps the two-pass kernels.  `tmp` must not alias either tensor in any form.
+    if (tmp == in || tmp == out) return SMIRK_ERR_BAD_ARG;
+    const bool lds_ok = staged <= 160 * 1024 && (size_t)B * ((H + MP_ROWS - 1) / MP_ROWS) < 0x7fffffffull && in != out;
+    if (lds_ok && radius == 10 && launch_maxpool_lds<10>(in, out, B, H, W, complement, (hipStream_t)stream)) return smirk_launch_status();
+    if (lds_ok && radius == 5 && launch_maxpool_lds<5>(in, out, B, H, W, complement, (hipStream_t)stream)) return smirk_launch_status();
     SMIRK_LAUNCH(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in, tmp, B, H, W, radius, 0, complement & 1, 0);
     SMIRK_LAUNCH(maxfilter1d_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, out, B, H, W, radius, 1, 0,
                        (complement >> 1) & 1);

@@ -117,19 +117,19 @@ def graph_cycle_modules(generator, encoder, generator_input, encoder_input, grad
     # tests/test_conv_gpu.py, never when the test ran alone).  The replayed graph is a chain either way — replay was measured SLOWER than eager launches
     # (DESIGN.md 8.9), this path exists for its host-time saving — so nothing is lost by recording the reference order.
     import gc
-    import os
     torch.cuda.synchronize()
     gc.collect()
     torch.cuda.empty_cache()
-    old = os.environ.get("SMIRK_ENCODER_TRAIN_SERIAL")
-    os.environ["SMIRK_ENCODER_TRAIN_SERIAL"] = "1"
+    if warmup < 1:
+        raise ValueError("graph_cycle_modules needs warmup >= 1: the first eager pass seals the weight-packing plans (a pageable host-to-device copy, illegal inside a capture)")
+    # the one-stream order is requested from THIS encoder object only (an attribute its forward reads), not through the process environment: other threads
+    # or modules running an encoder meanwhile keep their three streams
+    prev = getattr(encoder, "_train_serial", False)
+    encoder._train_serial = True
     try:
         return torch.cuda.make_graphed_callables((gen, enc), ((gi,), (ei,)), num_warmup_iters=warmup, allow_unused_input=True)
     finally:
-        if old is None:
-            del os.environ["SMIRK_ENCODER_TRAIN_SERIAL"]
-        else:
-            os.environ["SMIRK_ENCODER_TRAIN_SERIAL"] = old
+        encoder._train_serial = prev
 
 
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True, force_collective=False):

@@ -136,6 +136,7 @@ class BackboneTrainFunction(torch.autograd.Function):
             L.check(lib.smirk_expression_clamps(L.ptr(out), B, clamp_n_exp, st))
         if not plan.sealed:
             plan.seal(params, img.device)
+        ctx.plan, (ctx.plan_generation, ctx.plan_versions) = plan, plan.stamp(params)       # see PackPlan.check_tape
         ctx.backbone, ctx.head, ctx.tape = backbone, head, tape
         ctx.headrec = (hw_, pooled, raw, clamp_n_exp, (B, hf, wf, Cf, N))
         ctx.img_shape = (B, H, W)
@@ -147,6 +148,7 @@ class BackboneTrainFunction(torch.autograd.Function):
             raise RuntimeError("BackboneTrainFunction.backward called a second time: the tape of raw convolution outputs is released after the first "
                                "backward pass (retain_graph=True is not supported by the HIP training path; run the forward again)")
         backbone, head, tape = ctx.backbone, ctx.head, ctx.tape
+        ctx.plan.check_tape(ctx.plan_generation, ctx.plan_versions)
         hw_, pooled, raw, n_exp, (B, hf, wf, Cf, N) = ctx.headrec
         ops = _EncOps(raw.device)
         lib, st = ops.lib, ops.st

@@ -43,6 +43,7 @@ class _Ops:
         self.lib, self.st, self.dev = L.lib(), L.stream_ptr(), device
         self.eval_bn = bool(eval_bn)                     # BatchNorm from the running statistics (module in .eval() inside an autograd graph)
         self.plan = None
+        self.rm_saved = {}                                # eval-mode BatchNorm: id(bn) -> running_mean as the forward saw it
         self.red_ws = torch.empty(self.lib.smirk_train_reduce_workspace_bytes(1024), dtype=torch.uint8, device=device)
         self.wg_ws = None
 
@@ -93,11 +94,17 @@ class _Ops:
                 raise L.SmirkHipError("eval-mode BatchNorm needs running statistics (track_running_stats=True)")
             L.check(self.lib.smirk_bn_eval_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(bn.running_mean), P(bn.running_var),
                                                            P(residual, allow_none=True), int(relu), float(bn.eps), P(inv), P(mean), P(y), self.st))
+            # the backward re-derives the ReLU mask from (z - running_mean) * inv: it must see the running_mean of THIS forward even if a train-mode forward of
+            # the same module moves the buffer before the backward runs (C floats per layer)
+            self.rm_saved[id(bn)] = bn.running_mean.detach().clone()
             return y, mean, inv
         track = bn.running_mean is not None and bn.running_var is not None
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
         # nn.BatchNorm2d: momentum=None means a cumulative moving average, factor 1 / num_batches_tracked (after the increment above)
+        if bn.momentum is None and track and torch.cuda.is_current_stream_capturing():
+            raise L.SmirkHipError("BatchNorm2d(momentum=None) (cumulative average) cannot be captured into a HIP graph: its factor 1 / num_batches_tracked is a host "
+                                  "scalar read with a device synchronisation and would be frozen into the replay; use a numeric momentum (the reference does)")
         mom = float(bn.momentum) if bn.momentum is not None else (1.0 / max(int(bn.num_batches_tracked), 1) if track else 0.0)
         L.check(self.lib.smirk_bn_train_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
                                                         float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),
@@ -111,7 +118,7 @@ class _Ops:
         dz, dg, db = torch.empty_like(z), torch.empty(C, device=self.dev), torch.empty(C, device=self.dev)
         P = L.ptr
         if self.eval_bn:                                 # dz = gamma * invstd * dy * relu-mask; the affine parameters' gradients are not needed (frozen)
-            L.check(self.lib.smirk_bn_eval_backward_split16(P(z), P(dy), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(bn.running_mean), P(inv),
+            L.check(self.lib.smirk_bn_eval_backward_split16(P(z), P(dy), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(self.rm_saved.get(id(bn), bn.running_mean)), P(inv),
                                                             P(mean), int(relu), P(dz), self.st))
             return dz, None, None
         L.check(self.lib.smirk_bn_train_backward_split16(P(z), P(dy), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(mean), P(inv), int(relu), P(dz),
@@ -143,6 +150,22 @@ class PackPlan:
 
     def __init__(self):
         self.jobs, self.bufs, self.sealed, self.cursor, self.table, self.total = [], [], False, 0, None, 0
+        self.generation, self.versions = 0, None                     # which forward the buffers hold the weights of, and the weights' autograd versions then
+
+    def stamp(self, params):
+        """called by every forward after its weights are packed: (generation, versions) identify the buffer contents for that forward's tape"""
+        self.generation += 1
+        self.versions = tuple(int(p._version) for p in params)
+        return self.generation, self.versions
+
+    def check_tape(self, generation, versions):
+        """backward of the forward stamped (generation, versions): the plan-owned data-gradient weights must still hold THAT forward's weights.  A later forward
+        re-packs in place; that is harmless while the parameters are unchanged (identical images) and silently wrong once they were modified in between —
+        the situation torch autograd reports through its version counters, so it is reported the same way here."""
+        if generation != self.generation and versions != self.versions:
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: SmirkGenerator's weights changed "
+                               "after this forward and another forward of the same module has re-packed the plan-owned weight images since "
+                               "(run backward before the next forward of the module, or do not update its parameters in between)")
 
     def valid_for(self, params):
         return self.sealed and self.key == tuple((p.data_ptr(), tuple(p.shape)) for p in params)
@@ -269,6 +292,8 @@ class GeneratorTrainFunction(torch.autograd.Function):
         L.check(lib.smirk_conv1x1_sigmoid_nchw_split16(L.ptr(d), L.ptr(wf), L.ptr(bf), L.ptr(y), B, H, W, f, module.out_channels, st))
         if not plan.sealed:
             plan.seal(params, x.device)
+        ctx.plan, (ctx.plan_generation, ctx.plan_versions) = plan, plan.stamp(params)
+        ctx.rm_saved = ops.rm_saved
         ctx.module, ctx.tape, ctx.final = module, tape, (d, wf, y)
         ctx.shape = (B, Cx, H, W)
         return y
@@ -281,7 +306,9 @@ class GeneratorTrainFunction(torch.autograd.Function):
         module, tape, (d1, wf, y) = ctx.module, ctx.tape, ctx.final
         B, Cx, H, W = ctx.shape
         f = module.features
+        ctx.plan.check_tape(ctx.plan_generation, ctx.plan_versions)
         ops = _Ops(y.device, eval_bn=ctx.eval_bn)
+        ops.rm_saved = ctx.rm_saved
         lib, st = ops.lib, ops.st
         grads = {}                                                        # id(parameter) -> gradient in the parameter's layout
         # which parameters wanted a gradient WHEN THE FORWARD RAN (smirk_trainer.py:108-113 flips requires_grad off for the eval-mode forward and back on

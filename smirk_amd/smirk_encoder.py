@@ -379,7 +379,7 @@ class SmirkEncoder(nn.Module):
         # SMIRK_ENCODER_SERIAL: profiling aid (reference order on one stream).  Training uses the three streams as well unless SMIRK_ENCODER_TRAIN_SERIAL is
         # set: autograd runs every backward node on the stream its forward ran on and orders the streams itself, so the backbones' backward passes
         # interleave exactly like their forward passes (their ~1000 launches per step are small and latency-bound one after the other).
-        if os.environ.get("SMIRK_ENCODER_SERIAL") or (self.training and os.environ.get("SMIRK_ENCODER_TRAIN_SERIAL")):
+        if os.environ.get("SMIRK_ENCODER_SERIAL") or (self.training and (getattr(self, "_train_serial", False) or os.environ.get("SMIRK_ENCODER_TRAIN_SERIAL"))):
             for enc in (self.pose_encoder, self.shape_encoder, self.expression_encoder):
                 outputs.update(enc(img))
             return outputs

@@ -1,4 +1,5 @@
-"""Seeded synthetic assets and inputs for benchmarks, smoke runs and tests (no licence-gated data, no network).
+"""Seeded synthetic assets and inputs for benchmarks, smoke runs and tests (no licence-gated data, no network).  Bench / test helper at the repo root, next to
+bench.py: NOT part of the importable product (smirk_amd/ reads nothing under tests/).
 
 The reference reads its assets by cwd-relative path (FLAME.py:50-51,54,81-82,94,111; renderer.py:50,54,65).  The real
 FLAME2020/generic_model.pkl is licence-gated, so `write_sandbox` builds an ``assets/`` tree in the on-disk formats the loaders
@@ -11,7 +12,7 @@ import pickle
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.abspath(__file__))
 BUNDLE = os.path.join(REPO, "tests", "golden", "assets_bundle.npz")
 V = 5023
 F = 9976

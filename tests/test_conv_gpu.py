@@ -239,7 +239,8 @@ def test_enc1_fused_is_batch_invariant_and_deterministic():
 def test_generator_forward_with_and_without_the_fused_first_block(monkeypatch):
     """smirk_generator_forward takes enc1_fused.hip by default; SMIRK_DISABLE_ENC1_FUSED=1 restores the three launches — both within the generator tolerance of each other"""
     from oracle import generator_ref as G
-    from smirk_amd import SmirkGenerator, synth
+    from smirk_amd import SmirkGenerator
+    import synthdata as synth
     gsd = G.synth_state_dict()
     gen = SmirkGenerator(6, 3, 32, 5); gen.load_state_dict(gsd); gen = gen.cuda().eval()
     x = synth.synth_generator_input(2, seed=3).cuda()

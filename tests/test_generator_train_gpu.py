@@ -201,3 +201,43 @@ def test_one_launch_weight_packing_plan_equals_per_weight_packing():
     assert not torch.equal(third[0], first[0])
     m2 = _module(sd)                                              # new parameter storage -> new plan
     assert same(step(m2), first)
+
+
+def test_stale_tape_after_weight_update_and_another_forward_raises_like_autograd():
+    """the plan-owned data-gradient weight images are re-packed in place by every forward.  forward A -> in-place weight update ->
+    forward B -> backward A would silently back-propagate through B's weights; torch autograd raises a version-counter error there, and so does this path.
+    The two harmless orders still work: (i) forward A, forward B with UNCHANGED weights, backward A (smirk_trainer.py step1: train + eval forward);
+    (ii) weight update after A but no other forward before backward A."""
+    sd = G.synth_state_dict()
+    m = _module(sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 6, 32, 32, generator=g).cuda()
+
+    def fwd():
+        xx = x.clone().requires_grad_(True)
+        return xx, m(xx)
+
+    _, y0 = fwd(); y0.sum().backward()                             # records + seals the plan
+    # (i) two forwards on unchanged weights, backward of the FIRST: identical weight images -> allowed, and equal to a plain step
+    xa, ya = fwd()
+    xb, yb = fwd()
+    ya.sum().backward()
+    ref_x, ref_y = fwd(); ref_y.sum().backward()
+    assert torch.equal(xa.grad, ref_x.grad)
+    yb.sum().backward()
+    # (ii) update after the forward, backward straight away: the buffers still hold the forward's weights
+    xc, yc = fwd()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.001)
+    yc.sum().backward()
+    # (iii) forward A, update, forward B, backward A -> error (B's backward is fine)
+    xd, yd = fwd()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.001)
+    xe, ye = fwd()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        yd.sum().backward()
+    ye.sum().backward()
+    assert torch.isfinite(xe.grad).all()

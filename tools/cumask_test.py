@@ -4,7 +4,8 @@ import ctypes, os, sys, tempfile, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from smirk_amd import synth, masking
+from smirk_amd import masking
+import synthdata as synth
 from smirk_amd.pipeline import SmirkPipeline
 
 hip = ctypes.CDLL("libamdhip64.so")

@@ -37,7 +37,8 @@ if __name__ == "__main__":
         print(f"B={B:5d}  enc1 block: fused {fused:7.3f} ms ({fl / fused / 1e9:6.1f} TFLOP/s, {by / fused / 1e6:6.0f} GB/s algorithmic)   unfused (3 launches) {unf:7.3f} ms", flush=True)
         del d, xs
         if a.generator:
-            from smirk_amd import SmirkGenerator, synth
+            from smirk_amd import SmirkGenerator
+            import synthdata as synth
             gen = SmirkGenerator(6, 3, 32, 5); synth.he_init_(gen, seed=4321); gen = gen.cuda().eval()
             x = torch.rand(B, 6, 224, 224, device="cuda")
             with torch.no_grad():

@@ -2,7 +2,8 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import SmirkEncoder, synth
+from smirk_amd import SmirkEncoder
+import synthdata as synth
 from smirk_amd import _lib as L
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 167
 os.environ["SMIRK_ENCODER_SERIAL"] = "1"

@@ -3,7 +3,8 @@ import os, sys
 import torch
 os.environ["SMIRK_ENCODER_SERIAL"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import SmirkEncoder, synth
+from smirk_amd import SmirkEncoder
+import synthdata as synth
 from smirk_amd.smirk_encoder import MobileNetV3Features as MB
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 enc = SmirkEncoder().cuda().eval()

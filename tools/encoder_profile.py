@@ -6,7 +6,8 @@ import torch
 
 os.environ["SMIRK_ENCODER_SERIAL"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import SmirkEncoder, synth  # noqa: E402
+from smirk_amd import SmirkEncoder  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 enc = SmirkEncoder().cuda().eval()

@@ -57,7 +57,8 @@ def check(label):
 
 
 def main():
-    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, masking as MK, synth
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, masking as MK
+    import synthdata as synth
     from smirk_amd.pipeline import OverlappedPipeline, SmirkPipeline
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     sb = tempfile.mkdtemp()

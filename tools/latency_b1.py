@@ -7,7 +7,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, synth  # noqa: E402
+from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator  # noqa: E402
+import synthdata as synth  # noqa: E402
 from smirk_amd.pipeline import SmirkPipeline  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -1,7 +1,8 @@
 """Which generator layer goes wrong when a second generator runs concurrently on another stream? (debugging aid)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import synth, SmirkGenerator
+from smirk_amd import SmirkGenerator
+import synthdata as synth
 from oracle import generator_ref as G
 gen = SmirkGenerator(6, 3, 32, 5); gen.load_state_dict(G.synth_state_dict()); gen = gen.cuda().eval()
 g2 = SmirkGenerator(6, 3, 32, 5).cuda().eval()

@@ -25,7 +25,8 @@ def poisoned_empty(*size, **kw):
 
 
 def main():
-    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, masking as MK, synth
+    from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator, masking as MK
+    import synthdata as synth
     from smirk_amd.pipeline import SmirkPipeline
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     sb = tempfile.mkdtemp()

@@ -2,7 +2,7 @@
 import os, sys, tempfile, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import synth
+import synthdata as synth
 B = 128
 d = tempfile.mkdtemp(); synth.write_sandbox(d); os.chdir(d)
 from smirk_amd import FLAME, Renderer

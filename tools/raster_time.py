@@ -2,7 +2,8 @@
 import os, sys, tempfile
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import FLAME, Renderer, synth
+from smirk_amd import FLAME, Renderer
+import synthdata as synth
 from smirk_amd import _lib as L
 sb = tempfile.mkdtemp(); synth.write_sandbox(sb)
 cwd = os.getcwd(); os.chdir(sb)

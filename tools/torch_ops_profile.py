@@ -7,7 +7,7 @@ from torch.profiler import profile, ProfilerActivity
 dev = torch.device("cuda:0")
 sandbox = tempfile.mkdtemp()
 mods = bench.build_modules(sandbox, dev)
-from smirk_amd import synth
+import synthdata as synth
 from smirk_amd.pipeline import SmirkPipeline
 enc, flame, rend, gen = mods[:4]
 from smirk_amd import masking

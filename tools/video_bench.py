@@ -3,7 +3,7 @@
 import os, sys, tempfile, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smirk_amd import synth
+import synthdata as synth
 
 n, B = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), (int(sys.argv[2]) if len(sys.argv) > 2 else 64)
 d = tempfile.mkdtemp(); synth.write_sandbox(d); os.chdir(d)
