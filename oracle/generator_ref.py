@@ -50,7 +50,11 @@ def synth_state_dict(in_channels=6, out_channels=3, features=32, res_blocks=5, s
     conv("conv", out_channels, f, 1, bias=True)
     if calibrate:
         from .assets import synth_generator_input
-        forward(sd, synth_generator_input(4, seed=777), res_blocks, _calib=g)
+        if in_channels == 6:
+            xc = synth_generator_input(4, seed=777)
+        else:                                                        # other widths (tests of non-default shapes): a small seeded random batch
+            xc = torch.rand(2, in_channels, 64, 64, generator=torch.Generator().manual_seed(777))
+        forward(sd, xc, res_blocks, _calib=g)
     return sd
 
 

@@ -93,7 +93,7 @@ bool gen_args_ok(const SmirkGeneratorWeights* w, int B, int H, int W) {
     if (!w || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return false;
     if (w->res_blocks < 0 || w->res_blocks > SMIRK_GEN_MAX_RES || w->features <= 0 || w->out_channels <= 0 || w->out_channels > 4) return false;
     if (w->precision == SMIRK_PRECISION_F16X3) return w->features % 8 == 0 && w->cin_pad == 8 && w->in_channels <= 8;
-    return w->precision == SMIRK_PRECISION_F32 && w->features % 4 == 0 && w->cin_pad % 4 == 0 && w->cin_pad >= w->in_channels;
+    return w->precision == SMIRK_PRECISION_F32 && w->features % 8 == 0 && w->cin_pad % 4 == 0 && w->cin_pad >= w->in_channels;
 }
 
 }  // namespace

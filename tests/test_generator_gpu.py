@@ -101,3 +101,29 @@ def test_f16x3_range_check_flags_a_badly_scaled_checkpoint(monkeypatch):
             m(x)
         m.precision = "f32"                                        # the exact-fp32 mode carries them (no audit needed)
         assert torch.isfinite(m(x)).all()
+
+
+@pytest.mark.parametrize("cin,feat,res", [(10, 32, 2), (16, 16, 1), (12, 24, 1)])
+def test_generator_shapes_the_split_layout_cannot_carry_run_in_exact_fp32(cin, feat, res):
+    """the reference accepts any in_channels; more than 8 input channels (outside the split-fp16 input layout) are served by the exact-fp32 MFMA kernels instead
+    of being refused ('refuses shapes the reference accepts') — same output tolerance, also through forward_pair.  init_features % 8 != 0 stays a
+    loud refusal: tools/gen_shape_probe.py measured 12 / 20 features WRONG in the exact-fp32 mode that round 3 accepted them in."""
+    from smirk_amd import SmirkGenerator
+    sd = G.synth_state_dict(in_channels=cin, out_channels=3, features=feat, res_blocks=res, seed=77)
+    m = SmirkGenerator(in_channels=cin, out_channels=3, init_features=feat, res_blocks=res)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(cin * 100 + feat)
+    x = torch.rand(2, cin, 32, 48, generator=g)
+    y = G.forward(sd, x, res_blocks=res)
+    with torch.no_grad(), pytest.warns(UserWarning, match="exact-fp32"):
+        out = m(x.cuda())
+    assert (out.cpu() - y).abs().max().item() < OUT_TOL
+    with torch.no_grad():
+        k = cin // 2
+        out2 = m.forward_pair(x[:, :k].contiguous().cuda(), x[:, k:].contiguous().cuda())
+    assert torch.equal(out2, out)
+    with pytest.raises(Exception, match="multiple of 16"):                    # the reference's torch.cat fails on such sizes too
+        m(torch.rand(1, cin, 40, 40).cuda())
+    with pytest.raises(Exception, match="init_features % 8"):
+        SmirkGenerator(in_channels=6, out_channels=3, init_features=12, res_blocks=1)
