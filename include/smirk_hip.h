@@ -198,6 +198,12 @@ int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* 
  * activation never reaches HBM.  Returns SMIRK_ERR_UNSUPPORTED when the shape is not served by the halo-patch kernel (H, W % 16, H >= 64). */
 int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                              const float* shift, const float* fw, const float* fb, float* out_nchw, int fcout, void* stream);
+/* 3x3 conv (zero pad 1, stride 1, split16 in / out) + scale/shift + ReLU WITH the 2 x 2 / 2 max-pool of its output written by the same launch
+ * (smirk_generator.py:52-59: `enc2 = self.encoder2(...)`, `self.pool2(enc2)`): out [B][H][W][Cout], pooled [B][H/2][W/2][Cout], both split16.  Same
+ * descriptor as smirk_conv_igemm_f16x3.  Returns SMIRK_ERR_UNSUPPORTED when no kernel with a fused pool serves the shape (today: conv_ring.hip,
+ * Cout = 64, H, W multiples of 16 and >= 64, whole power-of-two 32-channel sources) — the caller then runs smirk_conv_igemm_f16x3 + smirk_maxpool2x2_split16. */
+int smirk_conv3x3_pool_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale, const float* shift, void* out,
+                             void* pooled, void* stream);
 /* The generator's FIRST encoder block in ONE launch (smirk_generator.py:52-53 `enc1 = self.encoder1(x)`, `self.pool1(enc1)`; _block :88-119 =
  * Conv2d(3x3, pad 1, bias=False) + BatchNorm2d + ReLU, twice): x [B][H][W][8] split16 (the packed network input, in_channels <= 8) ->
  * conv(8 -> 32) + scale1/shift1 + ReLU -> conv(32 -> 32) + scale2/shift2 + ReLU -> e1 [B][H][W][32] split16 (the skip tensor) and

@@ -110,6 +110,7 @@ _SIGS = {
     "smirk_conv_igemm_f32": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_conv_igemm_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_conv3x3_tail_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "smirk_conv3x3_pool_f16x3": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     "smirk_enc1_fused_supported": (_i, [_i, _i, _i, _i]),
     "smirk_enc1_fused_split16": (_i, [_p] * 9 + [_i, _i, _i, _p]),
     "smirk_f32_to_split16": (_i, [_p, _p, _sz, _p]),

@@ -624,6 +624,11 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
                                const float* shift, void* out, hipStream_t st, const float* fw, const float* fb, float* fout,
                                int fcout);
 
+// conv_ring.hip: 16 x 16 patches, weights streamed through an LDS ring, two workgroups per CU (Cout = 64 at 112 x 112), optional fused 2 x 2 max-pool
+bool smirk_conv3x3_ring64_eligible(const SmirkConvDesc* d, bool has_residual);
+int smirk_conv3x3_ring64_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale, const float* shift, void* out,
+                                void* pooled, hipStream_t st);
+
 static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                              const float* shift, const void* residual, void* out, void* stream, bool split);
 
@@ -682,6 +687,8 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
     hipStream_t st = (hipStream_t)stream;
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
+    if (split && smirk_conv3x3_ring64_eligible(d, residual != nullptr))                // conv_ring.hip: the 64-output-channel layers on large images
+        return smirk_conv3x3_ring64_launch(d, in0, in1, w, scale, shift, out, nullptr, st);
     if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
     if (split && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st);
@@ -705,6 +712,31 @@ extern "C" int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, co
 }
 
 // Network tail in one launch: conv3x3 (split16 in) + BN + ReLU + 1x1 conv (Cout 32 -> fcout <= 4) + bias + sigmoid -> NCHW fp32.
+// conv3x3 + BN + ReLU with the 2 x 2 max-pool of its output produced by the same launch (the U-Net's encoder blocks: `enc = block(x); pool(enc)`,
+// smirk_generator.py:52-59).  SMIRK_ERR_UNSUPPORTED when no kernel with a fused pool serves the shape (the caller then runs conv and pool separately).
+extern "C" int smirk_conv3x3_pool_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale, const float* shift, void* out,
+                                        void* pooled, void* stream) {
+    if (!d || !in0 || !w || !out || !pooled) return SMIRK_ERR_BAD_ARG;
+    if (d->C0 % 8 || d->C1 % 8 || (d->C1 > 0 && !in1) || d->H % 2 || d->W % 2) return SMIRK_ERR_BAD_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->C0 <= 0) return SMIRK_ERR_BAD_ARG;
+    const int bc = conv_batch_chunk(d, true);                      // batch chunks below 2 GiB each: eligibility is a property of the chunk
+    if (bc <= 0) return SMIRK_ERR_UNSUPPORTED;
+    {
+        SmirkConvDesc d0 = *d;
+        d0.B = d->B < bc ? d->B : bc;
+        if (d0.Cout != 64 || !smirk_conv3x3_ring64_eligible(&d0, false)) return SMIRK_ERR_UNSUPPORTED;
+    }
+    const size_t px = (size_t)d->H * d->W;
+    for (int b0 = 0; b0 < d->B; b0 += bc) {
+        SmirkConvDesc dc = *d;
+        dc.B = d->B - b0 < bc ? d->B - b0 : bc;
+        const int rc = smirk_conv3x3_ring64_launch(&dc, (const float*)in0 + b0 * px * d->C0, in1 ? (const float*)in1 + b0 * px * d->C1 : nullptr, w, scale, shift,
+                                                   (float*)out + b0 * px * d->Cout, (float*)pooled + b0 * (px / 4) * d->Cout, (hipStream_t)stream);
+        if (rc != SMIRK_OK) return rc;
+    }
+    return SMIRK_OK;
+}
+
 extern "C" int smirk_conv3x3_tail_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
                                         const float* shift, const float* fw, const float* fb, float* out_nchw, int fcout,
                                         void* stream) {

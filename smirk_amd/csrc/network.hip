@@ -147,6 +147,18 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         void* t1 = p.rot.pick(cur, nullptr);
         TRY(conv_call(split, desc3x3(B, h, wd, cin, 0, c, false, true), cur, nullptr, w->enc[l][0], nullptr, t1, stream));
         void* t2 = l < 4 ? p.e[l] : p.rot.pick(t1, nullptr);
+        if (l < 4 && split) {                                       // conv2 + BN + ReLU + pool in one launch where a kernel with a fused pool serves the shape
+            void* pl = p.rot.pick(t1, nullptr);
+            const SmirkConvDesc d2 = desc3x3(B, h, wd, c, 0, c, false, true);
+            const int rc = smirk_conv3x3_pool_f16x3(&d2, t1, nullptr, w->enc[l][1].w, w->enc[l][1].scale, w->enc[l][1].shift, t2, pl, stream);
+            if (rc == SMIRK_OK) {
+                tap(l, t2, act_bytes(B, h, wd, c));
+                cur = pl;
+                cin = c;
+                continue;
+            }
+            if (rc != SMIRK_ERR_UNSUPPORTED) return rc;
+        }
         TRY(conv_call(split, desc3x3(B, h, wd, c, 0, c, false, true), t1, nullptr, w->enc[l][1], nullptr, t2, stream));
         tap(l, t2, act_bytes(B, h, wd, c));
         if (l < 4) {

@@ -252,3 +252,52 @@ def test_generator_forward_with_and_without_the_fused_first_block(monkeypatch):
     assert (a - b).abs().max().item() < 2e-5
     y = G.forward(gsd, x.cpu())
     assert (a.cpu() - y).abs().max().item() < 2e-5
+
+
+# ---- conv_ring.hip: Cout = 64 on large images, weights streamed through an LDS ring, optional fused 2 x 2 max-pool ------------------------------------------
+RING_CASES = [dict(B=2, H=112, C0=32, C1=0, Cout=64), dict(B=3, H=112, C0=64, C1=0, Cout=64), dict(B=2, H=112, C0=64, C1=64, Cout=64),
+              dict(B=5, H=64, C0=128, C1=0, Cout=64), dict(B=1, H=64, C0=32, C1=32, Cout=64), dict(B=7, H=80, C0=64, C1=0, Cout=64),
+              dict(B=2, H=224, C0=32, C1=32, Cout=32), dict(B=3, H=64, C0=64, C1=0, Cout=32), dict(B=9, H=96, C0=32, C1=32, Cout=32)]   # Cout = 32, >= 2 chunks: three workgroups per CU
+
+
+@pytest.mark.parametrize("cfg", RING_CASES)
+def test_conv_ring64_matches_fp64_and_the_kernels_it_replaces(cfg, monkeypatch):
+    """1-4 channel chunks, one and two sources, patch counts below / above the persistent grid, a non-power-of-two image size: within the conv tolerance of torch
+    fp64 and within fp32 rounding of (bit-identical to, where that kernel walks K in the same order) the round-3 kernel for the shape ($SMIRK_CONV_RING=0)"""
+    from smirk_amd.smirk_generator import split16_to_float
+    ref, a = _run(**cfg, only_split=True)
+    monkeypatch.setenv("SMIRK_CONV_RING", "0")
+    _, b = _run(**cfg, only_split=True)
+    fa, fb = split16_to_float(a).cpu().double(), split16_to_float(b).cpu().double()
+    assert (fa - ref).abs().max().item() < TOL
+    assert (fa - fb).abs().max().item() < 1e-5
+    if cfg["Cout"] == 32 or cfg["C0"] + cfg["C1"] >= 128 or cfg["C0"] + cfg["C1"] == 32:     # round 3: streamed- / resident-weights patch kernels, same K order and MFMA sequence
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,C", [(2, 112, 64), (3, 64, 32), (9, 112, 64)])
+def test_conv3x3_pool_entry_equals_conv_then_pool(B, H, C):
+    """smirk_conv3x3_pool_f16x3: the conv output is bit-identical to smirk_conv_igemm_f16x3's and the pooled output to smirk_maxpool2x2_split16 of it"""
+    from smirk_amd import _lib as L
+    from smirk_amd.smirk_generator import _split16
+    lib, dev = L.lib(), torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 7 + C)
+    x = torch.randn(B, H, H, C, generator=g).to(dev)
+    w = (torch.randn(64, 9 * C, generator=g) * 0.05).to(dev)
+    sc, sh = (torch.rand(64, generator=g) + .5).to(dev), torch.randn(64, generator=g).to(dev)
+    P = L.ptr
+    xs = torch.empty_like(x)
+    L.check(lib.smirk_f32_to_split16(P(x), P(xs), x.numel(), L.stream_ptr()))
+    ws = _split16(w)
+    d = L.SmirkConvDesc()
+    d.B, d.H, d.W, d.C0, d.C1, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l = B, H, H, C, 0, 64, 3, 3, 1, 1, 1
+    d.Ho, d.Wo, d.pad_mode, d.act, d.out_mode = H, H, L.PAD_ZERO, L.ACT_RELU, L.OUT_NHWC
+    o0, o1 = torch.empty(B, H, H, 64, device=dev), torch.full((B, H, H, 64), float("nan"), device=dev)
+    p0, p1 = torch.empty(B, H // 2, H // 2, 64, device=dev), torch.full((B, H // 2, H // 2, 64), float("nan"), device=dev)
+    L.check(lib.smirk_conv_igemm_f16x3(d, P(xs), None, P(ws), P(sc), P(sh), None, P(o0), L.stream_ptr()))
+    L.check(lib.smirk_maxpool2x2_split16(P(o0), P(p0), B, H, H, 64, L.stream_ptr()))
+    L.check(lib.smirk_conv3x3_pool_f16x3(d, P(xs), None, P(ws), P(sc), P(sh), P(o1), P(p1), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(p0, p1)
+    d.Cout = 32                                                             # no kernel with a fused pool for this shape: the caller is told, nothing is launched
+    assert lib.smirk_conv3x3_pool_f16x3(d, P(xs), None, P(ws), P(sc), P(sh), P(o1), P(p1), L.stream_ptr()) == -4     # SMIRK_ERR_UNSUPPORTED

@@ -1,0 +1,9 @@
+#!/bin/bash
+TAG=${1:-r04g}
+OUT=/root/repo/gpurun_out; mkdir -p $OUT
+cd /root/repo
+timeout 900 python -m pytest tests/test_conv_gpu.py tests/test_generator_gpu.py -q -x > $OUT/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_pytest.log; tail -12 $OUT/${TAG}_pytest.log
+for B in 1024 128; do
+  echo "== B=$B ring (default)"; timeout 200 python tools/conv_sweep.py --batch $B --iters 5 --only 2 2>&1 | grep -v "amdgpu\|total\|up2"
+  echo "== B=$B SMIRK_CONV_RING=0"; SMIRK_CONV_RING=0 timeout 200 python tools/conv_sweep.py --batch $B --iters 5 --only 2 2>&1 | grep -v "amdgpu\|total\|up2"
+done | tee $OUT/${TAG}_ring_sweep.txt
