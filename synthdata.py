@@ -195,7 +195,7 @@ def calibrate_encoder_heads_(enc, device, seed=4242, n_exp=50):
     [0, 1]) — otherwise a random backbone's O(100) features drive FLAME into pathological meshes that no real frame produces (and that cost the
     rasteriser 50x its normal time).  Uses the product's own backbone forward on 16 synthetic frames; benchmark set-up only."""
     import torch
-    from .smirk_encoder import features_f32
+    from smirk_amd.smirk_encoder import features_f32
     g = torch.Generator().manual_seed(seed)
     x = synth_images(16, seed=seed).to(device)
     plan = ((enc.pose_encoder.encoder, enc.pose_encoder.pose_cam_layers[0], [0, 0, 0, 8, 0, 0], [.15, .15, .15, .7, .03, .03]),
