@@ -76,7 +76,9 @@ def parse_args(argv=None):
     ap.add_argument("--train-graphs", dest="train_graphs", action="store_true",
                     help="train64: replay the two CNNs' forward / backward from HIP graphs instead of launching kernel by kernel (measured: host enqueue 43 -> 27 ms "
                          "per step, but the replay of ~1300 chained kernel nodes runs 3.8 ms slower on the GPU, which is the bound: 53.1 vs 49.4 ms)")
-    ap.add_argument("--generator-streams", type=int, default=1, help="generator stages of consecutive micro-batches alternate over this many streams")
+    ap.add_argument("--generator-streams", type=int, default=None,
+                    help="generator stages of consecutive passes alternate over this many streams (default: 1 for passes of >= 512 frames, 2 below: the partial last "
+                         "round of a small pass's deep layers then overlaps the next pass's; measured +1.7 %% at 128 frames, -2 %% at 1024, profiles/r04c_*)")
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
     ap.add_argument("--cpu-faces", type=int, default=24, help="sample size of the CPU baseline (0 = skip)")
@@ -619,7 +621,7 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
                 "mfma_issue_frac": (3.0 if split else 1.0) * fl / tm / peak,
                 "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per product "
                          "(hi.hi, hi.lo, lo.hi), so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA at the nominal 2.4 GHz - a separate "
-                         "GRBM_GUI_ACTIVE pass (tools/pmc_clock.py, profiles/r03u_pmc_clock_full.txt; not re-measured by this run) found the deep-layer kernel "
+                         "GRBM_GUI_ACTIVE pass (tools/pmc_clock.py, profiles/r03u_pmc_clock_full.txt, round 3; not re-measured by this run) found the deep-layer kernel "
                          "running at 1.62 GHz under the power cap with its matrix pipe 0.81 busy at that clock") if split else
                         "achieved = algorithmic flop per launch / HIP-event launch time; peak = f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
     else:
@@ -640,6 +642,8 @@ def main():
     os.environ["SMIRK_BENCH_FLAME_BASIS"] = args.flame_basis     # read by build_modules (also in the ranks / rocprofv3 children this process launches)
     if args.micro_batch is None:
         args.micro_batch = MICRO_BATCH
+    if args.generator_streams is None:
+        args.generator_streams = 1 if min(args.micro_batch, per_rank_batch(args, max(1, int(os.environ.get("WORLD_SIZE", args.gpus))))) >= 512 else 2
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     import torch
@@ -797,6 +801,12 @@ def main():
             "output_stats": stats, "roofline": roof, "cpu_baseline": cpu}
         if args.plumbing_test:
             line["plumbing"] = {"gathered_ids_last": wl.seen[-1], "micro_batches_per_step": len(wl.slices), "gathers": len(wl.seen)}
+        try:                                 # RCCL prints its version banner through C stdio: flush it out BEFORE the JSON line, which stays the last line on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                    # noqa: BLE001
+            pass
+        sys.stdout.flush()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

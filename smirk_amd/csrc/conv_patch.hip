@@ -249,6 +249,16 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
 #pragma unroll
         for (int q = 0; q < 8; ++q) { ep_sc[q] = a.scale ? a.scale[g * 8 + q] : 1.f; ep_sh[q] = a.shift ? a.shift[g * 8 + q] : 0.f; }
     }
+    // fused network tail: the 1x1 conv's weights [4][COUT] (zero rows beyond fcout) and biases live in LDS behind the stages, staged ONCE per workgroup — read
+    // through a.fw inside the epilogue they were re-fetched from global memory for every item (the output stores may alias them as far as the compiler knows):
+    // 24 dependent-latency loads in front of each of a patch's four store groups.  (Registers are not an option: this instantiation sits at 256 VGPRs.)
+    float* const Tw = St + (GROUPS - group) * NST * PSTG;         // first float behind the last stage of the last group
+    if (TN == 1 && a.fout) {
+        for (int i = tid; i < 4 * COUT + 4; i += 256 * GROUPS) {
+            const int o = i / COUT, c = i - o * COUT;
+            Tw[i] = i < 4 * COUT ? (o < a.fcout ? a.fw[o * COUT + c] : 0.f) : ((i - 4 * COUT) < a.fcout && a.fb ? a.fb[i - 4 * COUT] : 0.f);
+        }
+    }
     const int ry = fr >> 4, rx = fr & 15;
     int item = (blockIdx.x * GROUPS + group) * a.nchunk;         // each 4-wave pipeline walks whole patches
     const int stride = gridDim.x * GROUPS * a.nchunk;
@@ -374,11 +384,11 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
                         // fused 1x1 conv + sigmoid: the 4 lanes e..e+3 hold one pixel's 4 channel groups -> partial dots + 2 xor shuffles
                         float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int o = 0; o < 4; ++o)
-                            if (o < a.fcout) {
+                        for (int o = 0; o < 4; ++o) {                 // outputs >= fcout carry zero weights
+                            const f32x4 w0 = *(const f32x4*)(Tw + o * COUT + g * 8), w1 = *(const f32x4*)(Tw + o * COUT + g * 8 + 4);
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) part[o] = fmaf(v[q], a.fw[o * COUT + g * 8 + q], part[o]);
-                            }
+                            for (int q = 0; q < 4; ++q) { part[o] = fmaf(v[q], w0[q], part[o]); part[o] = fmaf(v[4 + q], w1[q], part[o]); }
+                        }
 #pragma unroll
                         for (int o = 0; o < 4; ++o) {
                             part[o] += __shfl_xor(part[o], 1, 64);
@@ -386,9 +396,12 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
                         }
                         if (g == 0) {
                             const size_t HW = (size_t)a.H * a.W;
-                            for (int o = 0; o < a.fcout; ++o) {
-                                const float z = part[o] + (a.fb ? a.fb[o] : 0.f);
-                                a.fout[((size_t)b * a.fcout + o) * HW + (size_t)oy * a.W + ox] = 1.0f / (1.0f + expf(-z));
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) {
+                                if (o < a.fcout) {
+                                    const float z = part[o] + Tw[4 * COUT + o];
+                                    a.fout[((size_t)b * a.fcout + o) * HW + (size_t)oy * a.W + ox] = 1.0f / (1.0f + expf(-z));
+                                }
                             }
                         }
                     } else {
@@ -735,7 +748,7 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
         return smirk_launch_status();
     }
     const bool one_stage = (wbytes + (size_t)PSTAGE * 4) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
-    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4;
+    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4 + (fout ? (4 * 32 + 4) * 4 : 0);      // + the fused tail's 1x1 weights / biases
     static const char* cap_env = getenv("SMIRK_PATCH_CAP");
     const int cap = cap_env ? atoi(cap_env) : (one_stage ? 512 : 256);
     const int grid = a.npatch < cap ? a.npatch : cap;

@@ -9,7 +9,8 @@
 // input halo (12.8 KB) entirely inside the CU:
 //   conv1 on the 18 x 18 halo of the patch (halo RECOMPUTE, 1.27x of the cheap convolution) -> BN + ReLU -> split16 -> LDS (zero outside the image: it is
 //   conv2's zero padding) -> conv2 on the 16 x 16 patch from LDS -> BN + ReLU -> e1 and the pooled patch, both staged through LDS and stored as whole
-//   1 KiB runs of consecutive pixels.
+//   1 KiB runs of consecutive pixels (every lane storing its own 8-byte pieces straight to global memory was measured: 5.8 -> 6.4 ms per 1024 frames, the
+//   partner group's conv2 phase doubles while the store instructions drain; git history of this file).
 //   * conv1's K = 9 taps x 8 channels is packed TWO TAPS per 16-k MFMA step (a lane half = a tap): 5 steps instead of the 18 the generic patch kernel
 //     spends on a 32-channel chunk that is 3/4 zeros.
 //   * operands are swapped (weights first): the 32 x 32 accumulator then holds, per lane, 4 CONSECUTIVE CHANNELS x 4 groups of ONE pixel, so BN / ReLU /
@@ -34,9 +35,6 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
 #ifndef E1_PHASE_OFFSET
 #define E1_PHASE_OFFSET 1                           // 1: group 1 runs one phase behind group 0; 0: both groups in the same phase
-#endif
-#ifndef E1_DIRECT_STORES
-#define E1_DIRECT_STORES 0                         // epilogue 2: 1 = every lane stores its own 8-byte pieces, 0 = tiles staged through LDS and stored as 1 KiB runs
 #endif
 #define E1_PT 16                                  // output patch edge
 #define E1_IH (E1_PT + 2)                         // intermediate (conv1 output) halo edge: 18
@@ -445,31 +443,6 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                     unsigned hi[4], lo[4], phi[4], plo[4];
                     e1_split8(y, hi, lo);
                     e1_split8(pz, phi, plo);
-#if E1_DIRECT_STORES
-                    {   // each lane stores its own 8-byte pieces: a pixel's 128-byte line is completed by 8 instructions x 2 lane halves and merged in L2
-                        float* const o = a.e1 + (((size_t)b * H + oy0 + 4 * wave + 2 * i + ry) * W + ox0 + rx) * 32 + hb * 2;
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = hf * 2 + jj;
-                            const uint2v vh = {hi[2 * jj], hi[2 * jj + 1]}, vl = {lo[2 * jj], lo[2 * jj + 1]};
-                            *(uint2v*)(o + j * 8) = vh;
-                            *(uint2v*)(o + j * 8 + 4) = vl;
-                        }
-                        if (pool_lane) {
-                            float* const po = a.pool + (((size_t)b * (H >> 1) + ((oy0 + 4 * wave + 2 * i) >> 1)) * (W >> 1) + ((ox0 + rx) >> 1)) * 32 + hb * 2;
-#pragma unroll
-                            for (int jj = 0; jj < 2; ++jj) {
-                                const int j = hf * 2 + jj;
-                                const uint2v ph = {phi[2 * jj], phi[2 * jj + 1]}, pl = {plo[2 * jj], plo[2 * jj + 1]};
-                                *(uint2v*)(po + j * 8) = ph;
-                                *(uint2v*)(po + j * 8 + 4) = pl;
-                            }
-                        }
-                    }
-                    E1_FENCE();
-                }
-                if (i == 0) { E1_STAMP(14); E1_STAMP(15); }
-#else
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = hf * 2 + jj;
@@ -506,7 +479,6 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staging area is rewritten by the next tile
                 if (i == 0) E1_STAMP(15);
-#endif
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
