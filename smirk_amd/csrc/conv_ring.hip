@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
                         bl[s][j] = *(const half8*)(rg_lds + ((bv ^ cl) + (unsigned)(ST * STAGE + j * 4096)));
                     }
                 }
+                // matrix section at priority 1 (the other resident workgroup's loads / address arithmetic yield the issue slots): +0.5-3 % on the 64-channel
+                // instantiation, nothing on the 32-channel one (same-box A/B of a -DRG_SETPRIO build, round 4)
+                if constexpr (TN == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     rg_frag_ready(ah[s][1], al[s][1], bh[s][TN - 1], bl[s][TN - 1]);
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
                         for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc1[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (TN == 2) __builtin_amdgcn_s_setprio(0);
             };
             if (cc == 0) phase(std::integral_constant<int, 0>{}, std::true_type{});
             else phase(std::integral_constant<int, 0>{}, std::false_type{});

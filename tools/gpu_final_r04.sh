@@ -21,4 +21,9 @@ for wl in full train64; do
   if [ -n "$db" ]; then python /root/repo/tools/rocprof_summary.py $db $OUT/${TAG}_kernel_stats_$wl.txt "rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 2 --warmup 1 --no-roofline --cpu-faces 0" | head -14 | cut -c1-130; else echo "no db $wl"; tail -3 /tmp/rp_$wl.log; fi
 done
 cd /root/repo
-timeout 200 python tools/pmc_clock.py full $OUT/${TAG}_pmc_clock_full.txt > /dev/null 2>&1; head -20 $OUT/${TAG}_pmc_clock_full.txt 2>/dev/null | cut -c1-150
+# the clock pass runs the three backbones on ONE stream: GRBM_GUI_ACTIVE is a device-wide counter, so a kernel that overlaps kernels of other streams is charged
+# their cycles too (round 3's 589 M cycles for a 0.55 ms mbconv_image launch, rows above 2.4 GHz)
+SMIRK_ENCODER_SERIAL=1 timeout 200 python tools/pmc_clock.py full $OUT/${TAG}_pmc_clock_full.txt > /dev/null 2>&1; head -24 $OUT/${TAG}_pmc_clock_full.txt 2>/dev/null | cut -c1-150
+# phase timeline of enc1_fused (variant build with -DSMIRK_DEBUG_HOOKS, made in the build container) and the co-residency microbenchmarks quoted in DESIGN.md 10.1
+if [ -f smirk_amd/lib_fz/libsmirk_hip_variant.so ]; then SMIRK_HIP_LIBRARY=/root/repo/smirk_amd/lib_fz/libsmirk_hip_variant.so timeout 120 python tools/enc1_timeline.py 1024 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_enc1_timeline.txt; fi
+for m in valu_rate valu_mfma_share pool_probe; do [ -x tools/micro/$m ] && ./tools/micro/$m; done 2>&1 | tee $OUT/${TAG}_micro_valu_mfma_lds.txt | tail -12
