@@ -131,8 +131,7 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     // ---- encoder1..4 + bottleneck (smirk_generator.py:52-60) ---------------------------------------------------------------------------
     const void* cur = p.x;
     int cin = w->cin_pad;
-    const void* bott = nullptr;
-    for (int l = 0; l < 5; ++l) {
+    for (int l = 0; l < 3; ++l) {
         const int h = H >> l, wd = W >> l, c = f << l;
         if (l == 0 && split && smirk_enc1_fused_supported(cin, f, h, wd)) {
             // encoder1 + pool1 in one launch (enc1_fused.hip): the 32-channel full-resolution tensor between the two convolutions never reaches HBM
@@ -146,8 +145,8 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         }
         void* t1 = p.rot.pick(cur, nullptr);
         TRY(conv_call(split, desc3x3(B, h, wd, cin, 0, c, false, true), cur, nullptr, w->enc[l][0], nullptr, t1, stream));
-        void* t2 = l < 4 ? p.e[l] : p.rot.pick(t1, nullptr);
-        if (l < 4 && split) {                                       // conv2 + BN + ReLU + pool in one launch where a kernel with a fused pool serves the shape
+        void* t2 = p.e[l];
+        if (split) {                                       // conv2 + BN + ReLU + pool in one launch where a kernel with a fused pool serves the shape
             void* pl = p.rot.pick(t1, nullptr);
             const SmirkConvDesc d2 = desc3x3(B, h, wd, c, 0, c, false, true);
             const int rc = smirk_conv3x3_pool_f16x3(&d2, t1, nullptr, w->enc[l][1].w, w->enc[l][1].scale, w->enc[l][1].shift, t2, pl, stream);
@@ -161,29 +160,111 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         }
         TRY(conv_call(split, desc3x3(B, h, wd, c, 0, c, false, true), t1, nullptr, w->enc[l][1], nullptr, t2, stream));
         tap(l, t2, act_bytes(B, h, wd, c));
-        if (l < 4) {
-            void* pl = p.rot.pick(nullptr, nullptr);
-            TRY(pool(t2, pl, h, wd, c));
-            cur = pl;
-            cin = c;
-        } else {
-            bott = t2;
+        void* pl = p.rot.pick(nullptr, nullptr);
+        TRY(pool(t2, pl, h, wd, c));
+        cur = pl;
+        cin = c;
+    }
+    // ---- the deep section: encoder4 + pool4, bottleneck, ResNet blocks, upconv4 + decoder4 (smirk_generator.py:58-66, :121-178) — everything at H/8 and H/16 ----
+    // These launches rarely fill whole rounds of workgroups on the 256 CUs (14 x 14 x 512: 196 B / 256 tiles x 4 = 1.53 rounds at 128 frames = 2 rounds of time,
+    // 3.06 -> 4 at 256; the 28 x 28 layers likewise), and each waits for the one before it.  Frames are independent, so the section runs as TWO half-batch chains on
+    // two streams (the caller's and a library-owned side stream, forked / joined with events): while one chain's layer drains its partial last round the other
+    // chain's workgroups take the free CUs.  Bit-identical results (batch invariance, tests/test_scale_gpu.py); measured with the RCCL gather enqueued (same box, profiles/r04l_split_chains.txt):
+    // +3.2 % at 128 frames per pass, +4.5 % at 256, +1.2 % at 1024 -> taken when > 5 % of a 14 x 14 layer's last round would idle.  $SMIRK_GEN_SPLIT_CHAINS=0 / 1 force it.
+    const int h8 = H >> 3, w8 = W >> 3, c8 = f << 3, h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
+    auto poolh = [&](const void* in, void* out, int nb, int h, int wd, int c, void* strm) {
+        return split ? smirk_maxpool2x2_split16(in, out, nb, h, wd, c, strm) : smirk_maxpool2x2_nhwc((const float*)in, (float*)out, nb, h, wd, c, strm);
+    };
+    // Memory: the section's temporaries rotate through the three scratch slots, each sized for the largest tensor of the network (B x H x W x f elements = 8x the
+    // largest tensor of this section).  The two chains run at different paces and would otherwise put tensors of DIFFERENT shapes (so different frame offsets) into
+    // one slot at the same time: chain 1 keeps its temporaries in the UPPER HALF of every slot, indexed from frame 0; only the tensors that cross the section's
+    // boundary use the whole-batch layout (the pooled input, the skip tensor e4, the section's output) — their frame ranges are disjoint between the chains, and a
+    // chain's private region (<= B/2 x 0.8 MB per frame here) ends where the other chain's boundary frames begin or lies beyond them.
+    const size_t half_slot = act_bytes(B, H, W, f) / 2;
+    auto deep = [&](int chain, int b0, int nb, void* strm, const void* in3, const void*& out3) -> int {
+        auto nat = [&](const void* base, int h, int wd, int c) { return (const void*)((const char*)base + act_bytes(b0, h, wd, c)); };     // whole-batch layout
+        auto natw = [&](void* base, int h, int wd, int c) { return (void*)((char*)base + act_bytes(b0, h, wd, c)); };
+        auto at = [&](const void* base) { return (const void*)((const char*)base + (chain ? half_slot : 0)); };                              // chain-private
+        auto atw = [&](void* base) { return (void*)((char*)base + (chain ? half_slot : 0)); };
+        // encoder4 + pool4
+        void* t1 = p.rot.pick(in3, nullptr);
+        TRY(conv_call(split, desc3x3(nb, h8, w8, c8 / 2, 0, c8, false, true), nat(in3, h8, w8, c8 / 2), nullptr, w->enc[3][0], nullptr, atw(t1), strm));
+        TRY(conv_call(split, desc3x3(nb, h8, w8, c8, 0, c8, false, true), at(t1), nullptr, w->enc[3][1], nullptr, natw(p.e[3], h8, w8, c8), strm));
+        tap(3, p.e[3], act_bytes(B, h8, w8, c8));                   // (taps => single chain over the whole batch on the caller's stream)
+        void* pl = p.rot.pick(nullptr, nullptr);
+        TRY(poolh(nat(p.e[3], h8, w8, c8), atw(pl), nb, h8, w8, c8, strm));
+        // bottleneck
+        void* b1 = p.rot.pick(pl, nullptr);
+        TRY(conv_call(split, desc3x3(nb, h16, w16, c8, 0, c16, false, true), at(pl), nullptr, w->enc[4][0], nullptr, atw(b1), strm));
+        void* b2 = p.rot.pick(b1, nullptr);
+        TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, false, true), at(b1), nullptr, w->enc[4][1], nullptr, atw(b2), strm));
+        tap(4, b2, act_bytes(B, h16, w16, c16));
+        // ResNet blocks: reflect pad, conv-BN-ReLU, reflect pad, conv-BN, + x
+        const void* cur16 = b2;
+        for (int k = 0; k < w->res_blocks; ++k) {
+            void* t = p.rot.pick(cur16, nullptr);
+            TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, true, true), at(cur16), nullptr, w->res[k][0], nullptr, atw(t), strm));
+            void* o = p.rot.pick(cur16, t);
+            TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, true, false), at(t), nullptr, w->res[k][1], at(cur16), atw(o), strm));
+            cur16 = o;
+        }
+        tap(5, cur16, act_bytes(B, h16, w16, c16));
+        // upconv4 + decoder4 (two-source conv with the skip e4)
+        void* up = p.rot.pick(cur16, nullptr);
+        TRY(conv_call(split, desc1x1(nb, h16, w16, c16, c8, false, true), at(cur16), nullptr, w->up[0], nullptr, atw(up), strm));
+        void* d1 = p.rot.pick(up, nullptr);
+        TRY(conv_call(split, desc3x3(nb, h8, w8, c8, c8, c8, false, true), at(up), nat(p.e[3], h8, w8, c8), w->dec[0][0], nullptr, atw(d1), strm));
+        void* d2 = p.rot.pick(d1, in3);                             // not the slot of the section's input: the OTHER chain may still be reading its frames of it
+        TRY(conv_call(split, desc3x3(nb, h8, w8, c8, 0, c8, false, true), at(d1), nullptr, w->dec[0][1], nullptr, natw(d2, h8, w8, c8), strm));
+        tap(6, d2, act_bytes(B, h8, w8, c8));
+        out3 = d2;
+        return SMIRK_OK;
+    };
+    bool two_chains = false;
+    if (B >= 2 && !taps && !g_smirk_prof_on) {                      // (taps copy whole tensors; the launch profiler times launches on ONE stream)
+        static int n_cu = 0;
+        if (n_cu == 0) { int dev = 0, cus = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; n_cu = cus; }
+        const double rounds = ((double)B * h16 * w16 / 256.0) * (c16 / 128.0) / n_cu;      // 256 x 128 tiles of a 14 x 14 layer per CU
+        const double full = (double)(long long)(rounds + 0.999999);
+        two_chains = full > 0 && (full - rounds) / full > 0.05;
+        if (const char* e = getenv("SMIRK_GEN_SPLIT_CHAINS")) two_chains = e[0] != '0';
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (two_chains && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) two_chains = false;
+    hipStream_t side = nullptr;
+    if (two_chains) {
+        static hipStream_t side_dev[64] = {};                        // one side stream per device, created on first use
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) two_chains = false;
+        else {
+            if (!side_dev[dev] && hipStreamCreateWithFlags(&side_dev[dev], hipStreamNonBlocking) != hipSuccess) { side_dev[dev] = nullptr; two_chains = false; }
+            side = side_dev[dev];
         }
     }
-    // ---- ResNet blocks at H/16 (smirk_generator.py:62-63, :121-178): reflect pad, conv-BN-ReLU, reflect pad, conv-BN, + x -----------------
-    const int h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
-    const void* bcur = bott;
-    for (int k = 0; k < w->res_blocks; ++k) {
-        void* t = p.rot.pick(bcur, nullptr);
-        TRY(conv_call(split, desc3x3(B, h16, w16, c16, 0, c16, true, true), bcur, nullptr, w->res[k][0], nullptr, t, stream));
-        void* o = p.rot.pick(bcur, t);
-        TRY(conv_call(split, desc3x3(B, h16, w16, c16, 0, c16, true, false), t, nullptr, w->res[k][1], bcur, o, stream));
-        bcur = o;
+    const void* dcur = nullptr;
+    if (two_chains) {
+        hipEvent_t fork = nullptr, join = nullptr;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+            if (fork) (void)hipEventDestroy(fork);
+            return SMIRK_ERR_LAUNCH;
+        }
+        const int B0 = (B + 1) / 2;
+        const void *l0 = nullptr, *l1 = nullptr;
+        int rc = SMIRK_OK;
+        if (hipEventRecord(fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        if (rc == SMIRK_OK) rc = deep(1, B0, B - B0, (void*)side, cur, l1);
+        if (rc == SMIRK_OK && hipEventRecord(join, side) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        if (rc == SMIRK_OK) rc = deep(0, 0, B0, stream, cur, l0);
+        if (rc == SMIRK_OK && hipStreamWaitEvent((hipStream_t)stream, join, 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        (void)hipEventDestroy(fork);                                 // destruction is deferred until the recorded work has completed
+        (void)hipEventDestroy(join);
+        if (rc != SMIRK_OK) return rc;
+        dcur = l0;
+    } else {
+        TRY(deep(0, 0, B, stream, cur, dcur));
     }
-    tap(5, bcur, act_bytes(B, h16, w16, c16));
     // ---- decoder4..1 (smirk_generator.py:65-75): ConvTranspose2d k2 s2, cat with the skip (two-source conv), double conv -------------------
-    const void* dcur = bcur;
-    for (int l = 3; l >= 0; --l) {
+    for (int l = 2; l >= 0; --l) {
         const int h = H >> l, wd = W >> l, c = f << l;              // output resolution of this level
         void* up = p.rot.pick(dcur, nullptr);
         TRY(conv_call(split, desc1x1(B, h / 2, wd / 2, 2 * c, c, false, true), dcur, nullptr, w->up[3 - l], nullptr, up, stream));
