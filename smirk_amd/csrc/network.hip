@@ -167,8 +167,8 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     }
     // ---- the deep section: encoder4 + pool4, bottleneck, ResNet blocks, upconv4 + decoder4 (smirk_generator.py:58-66, :121-178) — everything at H/8 and H/16 ----
     // These launches rarely fill whole rounds of workgroups on the 256 CUs (14 x 14 x 512: 196 B / 256 tiles x 4 = 1.53 rounds at 128 frames = 2 rounds of time,
-    // 3.06 -> 4 at 256; the 28 x 28 layers likewise), and each waits for the one before it.  Frames are independent, so the section runs as TWO half-batch chains on
-    // two streams (the caller's and a library-owned side stream, forked / joined with events): while one chain's layer drains its partial last round the other
+    // 3.06 -> 4 at 256; the 28 x 28 layers likewise), and each waits for the one before it.  Frames are independent, so the section runs as TWO (optionally up to four) sub-batch chains on
+    // as many streams (the caller's and a library-owned side stream, forked / joined with events): while one chain's layer drains its partial last round the other
     // chain's workgroups take the free CUs.  Bit-identical results (batch invariance, tests/test_scale_gpu.py); measured with the RCCL gather enqueued (same box, profiles/r04l_split_chains.txt):
     // +3.2 % at 128 frames per pass, +4.5 % at 256, +1.2 % at 1024 -> taken when > 5 % of a 14 x 14 layer's last round would idle.  $SMIRK_GEN_SPLIT_CHAINS=0 / 1 force it.
     const int h8 = H >> 3, w8 = W >> 3, c8 = f << 3, h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
@@ -177,15 +177,16 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     };
     // Memory: the section's temporaries rotate through the three scratch slots, each sized for the largest tensor of the network (B x H x W x f elements = 8x the
     // largest tensor of this section).  The two chains run at different paces and would otherwise put tensors of DIFFERENT shapes (so different frame offsets) into
-    // one slot at the same time: chain 1 keeps its temporaries in the UPPER HALF of every slot, indexed from frame 0; only the tensors that cross the section's
+    // one slot at the same time: chain k keeps its temporaries in QUARTER k of every slot, indexed from frame 0; only the tensors that cross the section's
     // boundary use the whole-batch layout (the pooled input, the skip tensor e4, the section's output) — their frame ranges are disjoint between the chains, and a
-    // chain's private region (<= B/2 x 0.8 MB per frame here) ends where the other chain's boundary frames begin or lies beyond them.
-    const size_t half_slot = act_bytes(B, H, W, f) / 2;
+    // chain's private region (<= B/2 x 0.8 MB here; a quarter slot is B x 1.6 MB) ends where the other chains' boundary frames begin or lies beyond them.
+    const size_t slot_bytes = act_bytes(B, H, W, f);               // a chain's private region: slot + chain * slot_bytes / nchain_max(4)... see `priv` below
     auto deep = [&](int chain, int b0, int nb, void* strm, const void* in3, const void*& out3) -> int {
         auto nat = [&](const void* base, int h, int wd, int c) { return (const void*)((const char*)base + act_bytes(b0, h, wd, c)); };     // whole-batch layout
         auto natw = [&](void* base, int h, int wd, int c) { return (void*)((char*)base + act_bytes(b0, h, wd, c)); };
-        auto at = [&](const void* base) { return (const void*)((const char*)base + (chain ? half_slot : 0)); };                              // chain-private
-        auto atw = [&](void* base) { return (void*)((char*)base + (chain ? half_slot : 0)); };
+        const size_t priv = (slot_bytes / 4 * (size_t)chain) & ~(size_t)255;     // quarter k of every slot (up to four chains): >= the pooled input's and the output's whole-batch extent for k >= 1
+        auto at = [&](const void* base) { return (const void*)((const char*)base + priv); };                                                  // chain-private
+        auto atw = [&](void* base) { return (void*)((char*)base + priv); };
         // encoder4 + pool4
         void* t1 = p.rot.pick(in3, nullptr);
         TRY(conv_call(split, desc3x3(nb, h8, w8, c8 / 2, 0, c8, false, true), nat(in3, h8, w8, c8 / 2), nullptr, w->enc[3][0], nullptr, atw(t1), strm));
@@ -220,46 +221,51 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         out3 = d2;
         return SMIRK_OK;
     };
-    bool two_chains = false;
+    int nchain = 1;
     if (B >= 2 && !taps && !g_smirk_prof_on) {                      // (taps copy whole tensors; the launch profiler times launches on ONE stream)
         static int n_cu = 0;
         if (n_cu == 0) { int dev = 0, cus = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; n_cu = cus; }
         const double rounds = ((double)B * h16 * w16 / 256.0) * (c16 / 128.0) / n_cu;      // 256 x 128 tiles of a 14 x 14 layer per CU
         const double full = (double)(long long)(rounds + 0.999999);
-        two_chains = full > 0 && (full - rounds) / full > 0.05;
-        if (const char* e = getenv("SMIRK_GEN_SPLIT_CHAINS")) two_chains = e[0] != '0';
+        if (full > 0 && (full - rounds) / full > 0.05) nchain = 2;
+        if (const char* e = getenv("SMIRK_GEN_SPLIT_CHAINS")) nchain = (e[0] >= '0' && e[0] <= '4') ? (e[0] <= '1' ? (e[0] == '1' ? 2 : 1) : e[0] - '0') : nchain;   // 0: one chain, 1 / 2: two, 3, 4
+        if (nchain > B) nchain = B;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (two_chains && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) two_chains = false;
-    hipStream_t side = nullptr;
-    if (two_chains) {
-        static hipStream_t side_dev[64] = {};                        // one side stream per device, created on first use
+    if (nchain > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) nchain = 1;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    if (nchain > 1) {
+        static hipStream_t side_dev[64][3] = {};                     // side streams per device, created on first use
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) two_chains = false;
-        else {
-            if (!side_dev[dev] && hipStreamCreateWithFlags(&side_dev[dev], hipStreamNonBlocking) != hipSuccess) { side_dev[dev] = nullptr; two_chains = false; }
-            side = side_dev[dev];
-        }
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) nchain = 1;
+        else
+            for (int k = 0; k + 1 < nchain; ++k) {
+                if (!side_dev[dev][k] && hipStreamCreateWithFlags(&side_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { side_dev[dev][k] = nullptr; nchain = 1; break; }
+                side[k] = side_dev[dev][k];
+            }
     }
     const void* dcur = nullptr;
-    if (two_chains) {
-        hipEvent_t fork = nullptr, join = nullptr;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
-            if (fork) (void)hipEventDestroy(fork);
-            return SMIRK_ERR_LAUNCH;
+    if (nchain > 1) {
+        hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+        int rc = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess ? SMIRK_OK : SMIRK_ERR_LAUNCH;
+        for (int k = 0; rc == SMIRK_OK && k + 1 < nchain; ++k)
+            if (hipEventCreateWithFlags(&join[k], hipEventDisableTiming) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        if (rc == SMIRK_OK && hipEventRecord(fork, (hipStream_t)stream) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        const void* last = nullptr;
+        for (int k = nchain - 1; rc == SMIRK_OK && k >= 0; --k) {   // chain k owns frames [B k / n, B (k+1) / n); chain 0 runs on the caller's stream, enqueued last
+            const int b0 = (int)((long long)B * k / nchain), b1 = (int)((long long)B * (k + 1) / nchain);
+            hipStream_t st_k = k == 0 ? (hipStream_t)stream : side[k - 1];
+            if (k > 0 && hipStreamWaitEvent(st_k, fork, 0) != hipSuccess) { rc = SMIRK_ERR_LAUNCH; break; }
+            rc = deep(k, b0, b1 - b0, (void*)st_k, cur, last);
+            if (rc == SMIRK_OK && k > 0 && hipEventRecord(join[k - 1], st_k) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
         }
-        const int B0 = (B + 1) / 2;
-        const void *l0 = nullptr, *l1 = nullptr;
-        int rc = SMIRK_OK;
-        if (hipEventRecord(fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
-        if (rc == SMIRK_OK) rc = deep(1, B0, B - B0, (void*)side, cur, l1);
-        if (rc == SMIRK_OK && hipEventRecord(join, side) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
-        if (rc == SMIRK_OK) rc = deep(0, 0, B0, stream, cur, l0);
-        if (rc == SMIRK_OK && hipStreamWaitEvent((hipStream_t)stream, join, 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
-        (void)hipEventDestroy(fork);                                 // destruction is deferred until the recorded work has completed
-        (void)hipEventDestroy(join);
+        for (int k = 0; rc == SMIRK_OK && k + 1 < nchain; ++k)
+            if (hipStreamWaitEvent((hipStream_t)stream, join[k], 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        if (fork) (void)hipEventDestroy(fork);                       // destruction is deferred until the recorded work has completed
+        for (int k = 0; k < 3; ++k)
+            if (join[k]) (void)hipEventDestroy(join[k]);
         if (rc != SMIRK_OK) return rc;
-        dcur = l0;
+        dcur = last;
     } else {
         TRY(deep(0, 0, B, stream, cur, dcur));
     }
