@@ -326,7 +326,9 @@ def measure_traffic(args):
     if args.given_masked:
         inner.append("--given-masked")
     out = {}
-    env = dict(os.environ, TMPDIR="/tmp")
+    # the counter passes launch the generator's deep section as ONE chain, like the instrumented (launch-profiler) pass whose per-launch flop / bytes the
+    # traffic is compared with (the timed steps may run it as two half-batch chains: half-sized launches)
+    env = dict(os.environ, TMPDIR="/tmp", SMIRK_GEN_SPLIT_CHAINS="0")
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"smirk_pmc_{c}_", dir="/tmp")
         r = subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", d, "-o", "p", "--"] + inner, cwd="/tmp", env=env,
