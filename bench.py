@@ -38,6 +38,11 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# One hardware queue per HIP stream (read by the HIP runtime when it initialises, i.e. before `import torch` touches the device).  The pipeline uses up to 11
+# streams (front, 3 backbones, 2 generator streams with a chain side stream each, the gather / copy streams); the runtime's default of 4 hardware queues makes
+# streams SHARE a queue, whose packets retire in order — the 128-frame step's trace (profiles/r04o_timeline_shard128.txt) shows each backbone stream starting
+# only when a generator kernel of the queue it landed on had finished.  smirk_amd/__init__.py sets the same default for library users.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 FLOP_PER_FACE = 28.77e9          # encoder 0.929 G + FLAME 12.7 M + render ~2 M + generator 27.826 G
 FLOP_PER_FACE_INFER = 0.929e9 + 12.7e6 + 2e6
@@ -76,9 +81,12 @@ def parse_args(argv=None):
     ap.add_argument("--train-graphs", dest="train_graphs", action="store_true",
                     help="train64: replay the two CNNs' forward / backward from HIP graphs instead of launching kernel by kernel (measured: host enqueue 43 -> 27 ms "
                          "per step, but the replay of ~1300 chained kernel nodes runs 3.8 ms slower on the GPU, which is the bound: 53.1 vs 49.4 ms)")
+    ap.add_argument("--infer-lanes", type=int, default=1,
+                    help="infer256: consecutive batches rotate over this many streams (pipeline.RotatingPipeline; 1 = one batch at a time).  Measured equal: 39.7 / 39.4 / "
+                         "40.2 k faces/s with 1 / 2 / 3 lanes (profiles/r04r_infer_lanes.txt) - the step is bound by the GPU time of its kernels, not by its critical path")
     ap.add_argument("--generator-streams", type=int, default=None,
-                    help="generator stages of consecutive passes alternate over this many streams (default: 1 for passes of >= 512 frames, 2 below: the partial last "
-                         "round of a small pass's deep layers then overlaps the next pass's; measured +1.7 %% at 128 frames, -2 %% at 1024, profiles/r04c_*)")
+                    help="generator stages of consecutive passes alternate over this many streams (default 2: the partial last round of one pass's deep layers "
+                         "overlaps the next pass's; with one hardware queue per stream +6 %% at 128 frames, +1.5 %% at 1024, profiles/r04q_streams_chains.txt)")
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
     ap.add_argument("--cpu-faces", type=int, default=24, help="sample size of the CPU baseline (0 = skip)")
@@ -454,9 +462,10 @@ class InferWorkload(Workload):
     def __init__(self, args, dev, rank, world, sandbox):
         import torch
         import synthdata as synth
-        from smirk_amd.pipeline import SmirkPipeline
+        from smirk_amd.pipeline import RotatingPipeline, SmirkPipeline
         enc, flame, rend, _ = build_modules(sandbox, dev, want=("enc", "flame", "rend"))
         self.pipe = SmirkPipeline(enc, flame, rend, None)
+        self.runner = RotatingPipeline(self.pipe, lanes=args.infer_lanes) if args.infer_lanes > 1 else None
         self.B = per_rank_batch(args, world)
         mb = min(256, self.B)
         self.slices = [(i, min(i + mb, self.B)) for i in range(0, self.B, mb)]
@@ -464,9 +473,19 @@ class InferWorkload(Workload):
 
     def step(self):
         for lo, hi in self.slices:
-            self.last = self.pipe(self.img[lo:hi], with_landmarks=True)
+            if self.runner is None:
+                self.last = self.pipe(self.img[lo:hi], with_landmarks=True)
+            else:                                                 # batches are independent: batch i's raster tail overlaps batch i+1's backbones
+                done = self.runner.submit(self.img[lo:hi], with_landmarks=True)
+                self.last = done if done is not None else self.last
 
-    instrumented = step
+    def drain(self):
+        while self.runner is not None and (done := self.runner.flush()) is not None:
+            self.last = done
+
+    def instrumented(self):
+        for lo, hi in self.slices:
+            self.last = self.pipe(self.img[lo:hi], with_landmarks=True)
 
 
 class FlameWorkload(Workload):
@@ -645,7 +664,7 @@ def main():
     if args.micro_batch is None:
         args.micro_batch = MICRO_BATCH
     if args.generator_streams is None:
-        args.generator_streams = 1 if min(args.micro_batch, per_rank_batch(args, max(1, int(os.environ.get("WORLD_SIZE", args.gpus))))) >= 512 else 2
+        args.generator_streams = 2      # with one hardware queue per stream two generator streams win at every shard size (profiles/r04q_streams_chains.txt)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     import torch
@@ -796,7 +815,11 @@ def main():
                           {"schedule": ("forward + backward of the two CNNs replayed from four HIP graphs (torch.cuda.make_graphed_callables over the HIP autograd "
                                         "functions); FLAME / renderer / masking / loss / clip / Adam launched eagerly; roofline pass kernel by kernel"
                                         if getattr(wl, "graphs", False) else "every kernel launched from Python (ctypes)")}
-                          if args.workload == "train64" else {})},
+                          if args.workload == "train64" else
+                          {"schedule": (f"consecutive 256-frame batches rotate over {args.infer_lanes} streams (independent batches: the raster tail of batch i runs under the "
+                                        "backbones of batch i+1)" if args.infer_lanes > 1 else "one batch at a time")}
+                          if args.workload == "infer256" else {}),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "path_tflops_per_gpu": value / world * flop_face / 1e12,
             "path_frac_of_f16_mfma_peak": value / world * flop_face / PEAK_F16_MFMA,

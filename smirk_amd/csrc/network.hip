@@ -128,10 +128,44 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         if (taps && taps[i]) (void)hipMemcpyAsync(taps[i], src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     };
 
-    // ---- encoder1..4 + bottleneck (smirk_generator.py:52-60) ---------------------------------------------------------------------------
+    // ---- how the deep part of the network is launched (decided first: it sets where the whole-batch launches stop) ---------------------------------------------
+    // The layers at H/4 and below rarely fill whole rounds of workgroups on the 256 CUs (14 x 14 x 512: 196 B / 256 tiles x 4 = 1.53 rounds at 128 frames = 2 rounds
+    // of time, 3.06 -> 4 at 256; the 28 x 28 and 56 x 56 layers likewise), and each waits for the one before it.  Frames are independent, so this SECTION — encoder3,
+    // encoder4, bottleneck, ResNet blocks, decoder4, decoder3 — runs as TWO (optionally three) sub-batch chains on as many streams (the caller's and library-owned
+    // side streams, forked / joined with events): while one chain's layer drains its partial last round the other chain's workgroups take the free CUs.
+    // Bit-identical results (batch invariance, tests/test_scale_gpu.py run with it forced).  Measured with the RCCL gather enqueued, same box (profiles/r04l_, r04m_,
+    // r04n_): +3.2 % at 128 frames per pass, +4.5 % at 256, +1.2 % at 1024 for the H/8 + H/16 part -> taken when > 5 % of a 14 x 14 layer's last round would idle.
+    // $SMIRK_GEN_SPLIT_CHAINS=0 / 2 / 3 selects the number of chains, $SMIRK_GEN_CHAIN_FROM=2 / 3 the first level of the section: 3 (H/8) by default — starting at H/4
+    // measured 8,801 vs 8,857 faces/s at 128 frames, 9,406 vs 9,473 at 256, 9,872 vs 9,782 at 1024 (profiles/r04n_chain_from.txt): the 56 x 56 layers fill their rounds.
+    const int h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
+    int nchain = 1, L0 = 3;
+    if (const char* e = getenv("SMIRK_GEN_CHAIN_FROM")) L0 = e[0] == '3' ? 3 : 2;
+    if (B >= 2 && !taps && !g_smirk_prof_on) {                      // (taps copy whole tensors; the launch profiler times launches on ONE stream)
+        static int n_cu = 0;
+        if (n_cu == 0) { int dev = 0, cus = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; n_cu = cus; }
+        const double rounds = ((double)B * h16 * w16 / 256.0) * (c16 / 128.0) / n_cu;      // 256 x 128 tiles of a 14 x 14 layer per CU
+        const double full = (double)(long long)(rounds + 0.999999);
+        if (full > 0 && (full - rounds) / full > 0.05) nchain = 2;
+        if (const char* e = getenv("SMIRK_GEN_SPLIT_CHAINS")) nchain = e[0] == '0' ? 1 : e[0] == '3' ? 3 : 2;
+        if (nchain > B) nchain = B;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (nchain > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) nchain = 1;
+    hipStream_t side[2] = {nullptr, nullptr};
+    if (nchain > 1) {
+        static hipStream_t side_dev[64][2] = {};                     // side streams per device, created on first use
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) nchain = 1;
+        else
+            for (int k = 0; k + 1 < nchain; ++k) {
+                if (!side_dev[dev][k] && hipStreamCreateWithFlags(&side_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { side_dev[dev][k] = nullptr; nchain = 1; break; }
+                side[k] = side_dev[dev][k];
+            }
+    }
+    // ---- encoder levels above the section, whole batch (smirk_generator.py:52-57) --------------------------------------------------------------------------
     const void* cur = p.x;
     int cin = w->cin_pad;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < L0; ++l) {
         const int h = H >> l, wd = W >> l, c = f << l;
         if (l == 0 && split && smirk_enc1_fused_supported(cin, f, h, wd)) {
             // encoder1 + pool1 in one launch (enc1_fused.hip): the 32-channel full-resolution tensor between the two convolutions never reaches HBM
@@ -165,88 +199,69 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         cur = pl;
         cin = c;
     }
-    // ---- the deep section: encoder4 + pool4, bottleneck, ResNet blocks, upconv4 + decoder4 (smirk_generator.py:58-66, :121-178) — everything at H/8 and H/16 ----
-    // These launches rarely fill whole rounds of workgroups on the 256 CUs (14 x 14 x 512: 196 B / 256 tiles x 4 = 1.53 rounds at 128 frames = 2 rounds of time,
-    // 3.06 -> 4 at 256; the 28 x 28 layers likewise), and each waits for the one before it.  Frames are independent, so the section runs as TWO (optionally up to four) sub-batch chains on
-    // as many streams (the caller's and a library-owned side stream, forked / joined with events): while one chain's layer drains its partial last round the other
-    // chain's workgroups take the free CUs.  Bit-identical results (batch invariance, tests/test_scale_gpu.py); measured with the RCCL gather enqueued (same box, profiles/r04l_split_chains.txt):
-    // +3.2 % at 128 frames per pass, +4.5 % at 256, +1.2 % at 1024 -> taken when > 5 % of a 14 x 14 layer's last round would idle.  $SMIRK_GEN_SPLIT_CHAINS=0 / 1 force it.
-    const int h8 = H >> 3, w8 = W >> 3, c8 = f << 3, h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
+    // ---- the section (smirk_generator.py:56-68, :121-178) -----------------------------------------------------------------------------------------------
+    // Memory: temporaries rotate through the three scratch slots, each sized for the largest tensor of the network (B x H x W x f elements = 4x the largest tensor of
+    // this section).  The chains run at different paces and would otherwise put tensors of DIFFERENT shapes (so different frame offsets) into one slot at the same
+    // time: chain k keeps its temporaries in QUARTER k + 1 of every slot, indexed from frame 0; only the tensors that cross the section's boundary use the whole-batch
+    // layout — its input (the pooled tensor of the level above), the skip tensors, its output — which all lie inside quarter 0 with frame ranges that are disjoint
+    // between the chains; the output never shares a slot with the input (one chain may finish while another still reads its input frames).
+    const size_t quarter = (act_bytes(B, H, W, f) / 4) & ~(size_t)255;
     auto poolh = [&](const void* in, void* out, int nb, int h, int wd, int c, void* strm) {
         return split ? smirk_maxpool2x2_split16(in, out, nb, h, wd, c, strm) : smirk_maxpool2x2_nhwc((const float*)in, (float*)out, nb, h, wd, c, strm);
     };
-    // Memory: the section's temporaries rotate through the three scratch slots, each sized for the largest tensor of the network (B x H x W x f elements = 8x the
-    // largest tensor of this section).  The two chains run at different paces and would otherwise put tensors of DIFFERENT shapes (so different frame offsets) into
-    // one slot at the same time: chain k keeps its temporaries in QUARTER k of every slot, indexed from frame 0; only the tensors that cross the section's
-    // boundary use the whole-batch layout (the pooled input, the skip tensor e4, the section's output) — their frame ranges are disjoint between the chains, and a
-    // chain's private region (<= B/2 x 0.8 MB here; a quarter slot is B x 1.6 MB) ends where the other chains' boundary frames begin or lies beyond them.
-    const size_t slot_bytes = act_bytes(B, H, W, f);               // a chain's private region: slot + chain * slot_bytes / nchain_max(4)... see `priv` below
-    auto deep = [&](int chain, int b0, int nb, void* strm, const void* in3, const void*& out3) -> int {
-        auto nat = [&](const void* base, int h, int wd, int c) { return (const void*)((const char*)base + act_bytes(b0, h, wd, c)); };     // whole-batch layout
-        auto natw = [&](void* base, int h, int wd, int c) { return (void*)((char*)base + act_bytes(b0, h, wd, c)); };
-        const size_t priv = (slot_bytes / 4 * (size_t)chain) & ~(size_t)255;     // quarter k of every slot (up to four chains): >= the pooled input's and the output's whole-batch extent for k >= 1
-        auto at = [&](const void* base) { return (const void*)((const char*)base + priv); };                                                  // chain-private
-        auto atw = [&](void* base) { return (void*)((char*)base + priv); };
-        // encoder4 + pool4
-        void* t1 = p.rot.pick(in3, nullptr);
-        TRY(conv_call(split, desc3x3(nb, h8, w8, c8 / 2, 0, c8, false, true), nat(in3, h8, w8, c8 / 2), nullptr, w->enc[3][0], nullptr, atw(t1), strm));
-        TRY(conv_call(split, desc3x3(nb, h8, w8, c8, 0, c8, false, true), at(t1), nullptr, w->enc[3][1], nullptr, natw(p.e[3], h8, w8, c8), strm));
-        tap(3, p.e[3], act_bytes(B, h8, w8, c8));                   // (taps => single chain over the whole batch on the caller's stream)
-        void* pl = p.rot.pick(nullptr, nullptr);
-        TRY(poolh(nat(p.e[3], h8, w8, c8), atw(pl), nb, h8, w8, c8, strm));
-        // bottleneck
-        void* b1 = p.rot.pick(pl, nullptr);
-        TRY(conv_call(split, desc3x3(nb, h16, w16, c8, 0, c16, false, true), at(pl), nullptr, w->enc[4][0], nullptr, atw(b1), strm));
+    auto deep = [&](int chain, int b0, int nb, void* strm, const void* in, const void*& out) -> int {
+        const size_t priv = nchain > 1 ? quarter * (size_t)(chain + 1) : 0;
+        auto N = [&](const void* base, int h, int wd, int c) { return (const void*)((const char*)base + act_bytes(b0, h, wd, c)); };    // whole-batch layout
+        auto Nw = [&](void* base, int h, int wd, int c) { return (void*)((char*)base + act_bytes(b0, h, wd, c)); };
+        auto P = [&](const void* base) { return (const void*)((const char*)base + priv); };                                              // chain-private
+        auto Pw = [&](void* base) { return (void*)((char*)base + priv); };
+        const void* cur = in;
+        bool cur_nat = true;
+        int ci = f << (L0 - 1);
+        for (int l = L0; l < 4; ++l) {                              // encoder levels of the section: conv, conv -> skip tensor, pool
+            const int h = H >> l, wd = W >> l, c = f << l;
+            void* t1 = p.rot.pick(cur, nullptr);
+            TRY(conv_call(split, desc3x3(nb, h, wd, ci, 0, c, false, true), cur_nat ? N(cur, h, wd, ci) : P(cur), nullptr, w->enc[l][0], nullptr, Pw(t1), strm));
+            TRY(conv_call(split, desc3x3(nb, h, wd, c, 0, c, false, true), P(t1), nullptr, w->enc[l][1], nullptr, Nw(p.e[l], h, wd, c), strm));
+            tap(l, p.e[l], act_bytes(B, h, wd, c));                 // (taps => one chain over the whole batch on the caller's stream)
+            void* pl = p.rot.pick(nullptr, nullptr);
+            TRY(poolh(N(p.e[l], h, wd, c), Pw(pl), nb, h, wd, c, strm));
+            cur = pl; cur_nat = false; ci = c;
+        }
+        const int c8 = f << 3;
+        void* b1 = p.rot.pick(cur, nullptr);                        // bottleneck
+        TRY(conv_call(split, desc3x3(nb, h16, w16, c8, 0, c16, false, true), P(cur), nullptr, w->enc[4][0], nullptr, Pw(b1), strm));
         void* b2 = p.rot.pick(b1, nullptr);
-        TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, false, true), at(b1), nullptr, w->enc[4][1], nullptr, atw(b2), strm));
+        TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, false, true), P(b1), nullptr, w->enc[4][1], nullptr, Pw(b2), strm));
         tap(4, b2, act_bytes(B, h16, w16, c16));
-        // ResNet blocks: reflect pad, conv-BN-ReLU, reflect pad, conv-BN, + x
-        const void* cur16 = b2;
+        const void* cur16 = b2;                                     // ResNet blocks: reflect pad, conv-BN-ReLU, reflect pad, conv-BN, + x
         for (int k = 0; k < w->res_blocks; ++k) {
             void* t = p.rot.pick(cur16, nullptr);
-            TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, true, true), at(cur16), nullptr, w->res[k][0], nullptr, atw(t), strm));
+            TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, true, true), P(cur16), nullptr, w->res[k][0], nullptr, Pw(t), strm));
             void* o = p.rot.pick(cur16, t);
-            TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, true, false), at(t), nullptr, w->res[k][1], at(cur16), atw(o), strm));
+            TRY(conv_call(split, desc3x3(nb, h16, w16, c16, 0, c16, true, false), P(t), nullptr, w->res[k][1], P(cur16), Pw(o), strm));
             cur16 = o;
         }
         tap(5, cur16, act_bytes(B, h16, w16, c16));
-        // upconv4 + decoder4 (two-source conv with the skip e4)
-        void* up = p.rot.pick(cur16, nullptr);
-        TRY(conv_call(split, desc1x1(nb, h16, w16, c16, c8, false, true), at(cur16), nullptr, w->up[0], nullptr, atw(up), strm));
-        void* d1 = p.rot.pick(up, nullptr);
-        TRY(conv_call(split, desc3x3(nb, h8, w8, c8, c8, c8, false, true), at(up), nat(p.e[3], h8, w8, c8), w->dec[0][0], nullptr, atw(d1), strm));
-        void* d2 = p.rot.pick(d1, in3);                             // not the slot of the section's input: the OTHER chain may still be reading its frames of it
-        TRY(conv_call(split, desc3x3(nb, h8, w8, c8, 0, c8, false, true), at(d1), nullptr, w->dec[0][1], nullptr, natw(d2, h8, w8, c8), strm));
-        tap(6, d2, act_bytes(B, h8, w8, c8));
-        out3 = d2;
+        const void* dc = cur16;
+        for (int l = 3; l >= L0; --l) {                             // decoder levels of the section: ConvTranspose2d, two-source conv with the skip, conv
+            const int h = H >> l, wd = W >> l, c = f << l;
+            void* up = p.rot.pick(dc, nullptr);
+            TRY(conv_call(split, desc1x1(nb, h / 2, wd / 2, 2 * c, c, false, true), P(dc), nullptr, w->up[3 - l], nullptr, Pw(up), strm));
+            void* d1 = p.rot.pick(up, nullptr);
+            TRY(conv_call(split, desc3x3(nb, h, wd, c, c, c, false, true), P(up), N(p.e[l], h, wd, c), w->dec[3 - l][0], nullptr, Pw(d1), strm));
+            const bool last = l == L0;
+            void* d2 = last ? p.rot.pick(d1, in) : p.rot.pick(d1, nullptr);
+            TRY(conv_call(split, desc3x3(nb, h, wd, c, 0, c, false, true), P(d1), nullptr, w->dec[3 - l][1], nullptr, last ? Nw(d2, h, wd, c) : Pw(d2), strm));
+            tap(6 + (3 - l), d2, act_bytes(B, h, wd, c));
+            dc = d2;
+        }
+        out = dc;
         return SMIRK_OK;
     };
-    int nchain = 1;
-    if (B >= 2 && !taps && !g_smirk_prof_on) {                      // (taps copy whole tensors; the launch profiler times launches on ONE stream)
-        static int n_cu = 0;
-        if (n_cu == 0) { int dev = 0, cus = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; n_cu = cus; }
-        const double rounds = ((double)B * h16 * w16 / 256.0) * (c16 / 128.0) / n_cu;      // 256 x 128 tiles of a 14 x 14 layer per CU
-        const double full = (double)(long long)(rounds + 0.999999);
-        if (full > 0 && (full - rounds) / full > 0.05) nchain = 2;
-        if (const char* e = getenv("SMIRK_GEN_SPLIT_CHAINS")) nchain = (e[0] >= '0' && e[0] <= '4') ? (e[0] <= '1' ? (e[0] == '1' ? 2 : 1) : e[0] - '0') : nchain;   // 0: one chain, 1 / 2: two, 3, 4
-        if (nchain > B) nchain = B;
-    }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (nchain > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) nchain = 1;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    if (nchain > 1) {
-        static hipStream_t side_dev[64][3] = {};                     // side streams per device, created on first use
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) nchain = 1;
-        else
-            for (int k = 0; k + 1 < nchain; ++k) {
-                if (!side_dev[dev][k] && hipStreamCreateWithFlags(&side_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { side_dev[dev][k] = nullptr; nchain = 1; break; }
-                side[k] = side_dev[dev][k];
-            }
-    }
     const void* dcur = nullptr;
     if (nchain > 1) {
-        hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
         int rc = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess ? SMIRK_OK : SMIRK_ERR_LAUNCH;
         for (int k = 0; rc == SMIRK_OK && k + 1 < nchain; ++k)
             if (hipEventCreateWithFlags(&join[k], hipEventDisableTiming) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
@@ -262,7 +277,7 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         for (int k = 0; rc == SMIRK_OK && k + 1 < nchain; ++k)
             if (hipStreamWaitEvent((hipStream_t)stream, join[k], 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
         if (fork) (void)hipEventDestroy(fork);                       // destruction is deferred until the recorded work has completed
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 2; ++k)
             if (join[k]) (void)hipEventDestroy(join[k]);
         if (rc != SMIRK_OK) return rc;
         dcur = last;
@@ -270,7 +285,7 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
         TRY(deep(0, 0, B, stream, cur, dcur));
     }
     // ---- decoder4..1 (smirk_generator.py:65-75): ConvTranspose2d k2 s2, cat with the skip (two-source conv), double conv -------------------
-    for (int l = 2; l >= 0; --l) {
+    for (int l = L0 - 1; l >= 0; --l) {                              // decoder levels above the section, whole batch
         const int h = H >> l, wd = W >> l, c = f << l;              // output resolution of this level
         void* up = p.rot.pick(dcur, nullptr);
         TRY(conv_call(split, desc1x1(B, h / 2, wd / 2, 2 * c, c, false, true), dcur, nullptr, w->up[3 - l], nullptr, up, stream));

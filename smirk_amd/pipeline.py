@@ -6,6 +6,9 @@ Frames are independent, every constant is replicated (~163 MB) and there is NO e
 sharded in contiguous slices, one process per GPU; the only collective is an all-gather of the outputs (vertices, rendered and
 re-synthesised images) over RCCL/xGMI, issued asynchronously so it overlaps the next batch's compute.
 """
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -69,6 +72,12 @@ class OverlappedPipeline:
     def __init__(self, pipe, generator_streams=1):
         self.pipe = pipe
         self.n_gen = int(generator_streams)
+        import smirk_amd
+        if smirk_amd.HW_QUEUES_TOO_LATE or int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 + 2 * self.n_gen:
+            warnings.warn("OverlappedPipeline runs on %d HIP streams but the HIP runtime multiplexes them onto %s hardware queues (packets of a shared queue "
+                          "retire in order): export GPU_MAX_HW_QUEUES=16 before the process first touches the GPU (smirk_amd sets it when imported first)"
+                          % (5 + 2 * self.n_gen, "4 (its default, read before smirk_amd was imported)" if smirk_amd.HW_QUEUES_TOO_LATE
+                             else os.environ.get("GPU_MAX_HW_QUEUES")), stacklevel=2)
         self.front_stream, self.gen_streams = None, None
         self._waiting = []                         # front done, generator not enqueued yet: (outputs, masked, front-done event)
         self._running = []                         # generator enqueued: (outputs, generator-done event), oldest first
@@ -146,6 +155,58 @@ class OverlappedPipeline:
         """next finished batch in submission order, None when the pipeline is empty"""
         self._start_generators()
         return self._pop_finished(0)
+
+
+class RotatingPipeline:
+    """Consecutive, independent frame batches of a generator-less SmirkPipeline (encode -> FLAME -> render: demo.py:107-112 in a loop) on `lanes` HIP streams in
+    rotation, so that the thinly occupied tail of batch i (raster_tile: 1.5 workgroups per CU at 256 frames) runs while the backbones of batch i+1 have already
+    started.  Same kernels, same inputs, results identical to SmirkPipeline.__call__; only the interleaving on the GPU changes.
+
+        run = RotatingPipeline(pipe, lanes=2)
+        for img in batches:
+            done = run.submit(img)              # -> outputs of the batch submitted `lanes - 1` calls earlier (None while the pipeline fills)
+        while (last := run.flush()) is not None: ...
+    """
+    _STREAMS = {}
+
+    def __init__(self, pipe, lanes=2):
+        if pipe.generator is not None:
+            raise ValueError("RotatingPipeline is the generator-less schedule; use OverlappedPipeline for encode -> ... -> generate")
+        self.pipe, self.lanes = pipe, max(1, int(lanes))
+        self._running, self._count = [], 0
+
+    def _pop(self, keep):
+        if len(self._running) <= keep:
+            return None
+        out, done = self._running.pop(0)
+        caller = torch.cuda.current_stream()
+        caller.wait_event(done)
+        for t in out.values():
+            if torch.is_tensor(t):
+                t.record_stream(caller)
+        return out
+
+    @torch.no_grad()
+    def submit(self, img, with_landmarks=True):
+        key = (img.device, self.lanes)
+        if key not in self._STREAMS:
+            self._STREAMS[key] = [torch.cuda.Stream(device=img.device) for _ in range(self.lanes)]
+        lane = self._STREAMS[key][self._count % self.lanes]
+        self._count += 1
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())               # the input was produced on the caller's stream
+        with torch.cuda.stream(lane):
+            lane.wait_event(ready)
+            out = self.pipe(img, with_landmarks=with_landmarks)
+            img.record_stream(lane)
+            done = torch.cuda.Event()
+            done.record(lane)
+        self._running.append((out, done))
+        return self._pop(self.lanes - 1)
+
+    def flush(self):
+        """next finished batch in submission order, None when the pipeline is empty"""
+        return self._pop(0)
 
 
 class OutputGatherer:

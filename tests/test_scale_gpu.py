@@ -172,6 +172,30 @@ def test_full_pipeline_B128_repeated_serial_and_overlapped(mods):
                 assert torch.equal(a[k], b[k]), (trial, k)
 
 
+def test_rotating_pipeline_B128_identical_to_one_batch_at_a_time(mods):
+    """BASELINE config 3's schedule in bench.py: consecutive generator-less batches rotate over 2 / 3 streams (the raster tail of batch i under the backbones
+    of batch i+1).  Same kernels, same inputs: every output bit-identical to SmirkPipeline.__call__, in submission order, over repeated rounds."""
+    from smirk_amd.pipeline import RotatingPipeline, SmirkPipeline
+    pipe = SmirkPipeline(mods["enc"], mods["flame"], mods["rend"], None)
+    batches = [A.synth_images(128, seed=s).cuda() for s in (7101, 7102, 7103)]
+    keys = ("vertices", "rendered_img", "cam", "landmarks_fan", "landmarks_mp", "expression_params", "shape_params", "pose_params")
+    first = [pipe(i) for i in batches]
+    torch.cuda.synchronize()
+    for lanes in (2, 3, 2):
+        run = RotatingPipeline(pipe, lanes=lanes)
+        got = [run.submit(i) for i in batches + batches]
+        while (o := run.flush()) is not None:
+            got.append(o)
+        got = [o for o in got if o is not None]
+        assert len(got) == 6
+        torch.cuda.synchronize()
+        for a, b in zip(first + first, got):
+            for k in keys:
+                assert torch.equal(a[k], b[k]), (lanes, k)
+    with pytest.raises(ValueError):
+        RotatingPipeline(SmirkPipeline(mods["enc"], mods["flame"], mods["rend"], mods["gen"]))
+
+
 def test_pipeline_hull_mask_path_finite_B128(mods, sandbox):
     """the masking utilities inside the step (demo.py:138-165) at the bench batch: finite, masked image is a sub-set of the photo's pixels
     plus sampled points, output in (0,1)."""
