@@ -393,10 +393,11 @@ int smirk_backbone_forward(const SmirkBackboneWeights* w, const float* img, int 
  * ------------------------------------------------------------------------------------------------------------------ */
 size_t smirk_train_reduce_workspace_bytes(int C);
 /* y = [relu]((z - mean_batch) / sqrt(var_batch + eps) * gamma + beta [+ residual]);  saves mean / biased var / invstd for the backward pass and updates
- * running_mean / running_var (nullable) with `momentum` (running_var takes the unbiased variance), exactly like F.batch_norm(training=True). */
+ * running_mean / running_var (nullable) with `momentum` (running_var takes the unbiased variance), exactly like F.batch_norm(training=True);
+ * num_batches_tracked (nullable, device int64 scalar) is incremented by the same launch (nn.BatchNorm2d.forward's `num_batches_tracked.add_(1)`). */
 int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu, float eps,
-                                   float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var, float* save_invstd,
-                                   void* y, void* ws, size_t ws_bytes, void* stream);
+                                   float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, float* save_mean,
+                                   float* save_var, float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream);
 /* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
 int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);

@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _p = C.c_void_p
 _i = C.c_int
@@ -135,7 +135,7 @@ _SIGS = {
     "smirk_backbone_workspace_bytes": (_sz, [C.POINTER(SmirkBackboneWeights), _i, _i, _i]),
     "smirk_backbone_forward": (_i, [C.POINTER(SmirkBackboneWeights), _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
-    "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_eval_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _p, _p, _i, C.c_float, _p, _p, _p, _p]),
     "smirk_bn_eval_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _p, _i, _p, _p]),

@@ -158,8 +158,9 @@ __device__ __forceinline__ bool stage2_sum(const double* __restrict__ part, int 
 // MODE 0: mean, biased variance, invstd, running-stat update (momentum; running_var takes the unbiased variance)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblocks, int C, double n, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt) {
     __shared__ double red[16][16][2];
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;          // nn.BatchNorm2d.forward: num_batches_tracked.add_(1) (one launch less per layer)
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
     double a, b;
     if (!stage2_sum(part, nblocks, C, c, a, b, red)) return;
@@ -1025,8 +1026,8 @@ extern "C" int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin
 extern "C" size_t smirk_train_reduce_workspace_bytes(int C) { return (size_t)RED_BLOCKS * (size_t)C * 2 * sizeof(double); }
 
 extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
-                                              float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_var,
-                                              float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream) {
+                                              float eps, float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                              float* save_mean, float* save_var, float* save_invstd, void* y, void* ws, size_t ws_bytes, void* stream) {
     if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !ws || M == 0 || C <= 0 || C % 8 || C / 8 > 256) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1036,7 +1037,7 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
                  (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
-                 save_invstd, running_mean, running_var);
+                 save_invstd, running_mean, running_var, num_batches_tracked);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
     SMIRK_LAUNCH(bn_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, M, G, (const float*)save_mean,
                  (const float*)save_invstd, gamma, beta, (const float*)residual, relu, (float*)y);

@@ -99,8 +99,10 @@ class _Ops:
             self.rm_saved[id(bn)] = bn.running_mean.detach().clone()
             return y, mean, inv
         track = bn.running_mean is not None and bn.running_var is not None
-        if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        nbt = bn.num_batches_tracked if track else None
+        if nbt is not None and (bn.momentum is None or nbt.dtype != torch.int64 or not nbt.is_cuda):
+            nbt += 1                                     # the cumulative average needs the count on the host; otherwise the kernel below increments it
+            nbt = None
         # nn.BatchNorm2d: momentum=None means a cumulative moving average, factor 1 / num_batches_tracked (after the increment above)
         if bn.momentum is None and track and torch.cuda.is_current_stream_capturing():
             raise L.SmirkHipError("BatchNorm2d(momentum=None) (cumulative average) cannot be captured into a HIP graph: its factor 1 / num_batches_tracked is a host "
@@ -108,7 +110,8 @@ class _Ops:
         mom = float(bn.momentum) if bn.momentum is not None else (1.0 / max(int(bn.num_batches_tracked), 1) if track else 0.0)
         L.check(self.lib.smirk_bn_train_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
                                                         float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),
-                                                        P(bn.running_var if track else None, allow_none=True), P(mean), P(var), P(inv), P(y),
+                                                        P(bn.running_var if track else None, allow_none=True), P(nbt, torch.int64, allow_none=True), P(mean), P(var),
+                                                        P(inv), P(y),
                                                         P(self.red_ws, torch.uint8), self.red_ws.numel(), self.st))
         return y, mean, inv
 

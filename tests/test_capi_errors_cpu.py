@@ -38,10 +38,10 @@ def test_weight_gradient_rejects_bad_shapes_and_small_workspace(lib):
 def test_batchnorm_train_entries(lib):
     need = lib.smirk_train_reduce_workspace_bytes(64)
     fwd, bwd, cs = lib.smirk_bn_train_forward_split16, lib.smirk_bn_train_backward_split16, lib.smirk_colsum_split16
-    args = lambda C_, ws: (P, 128, C_, P, P, None, 1, 1e-5, 0.1, P, P, P, P, P, P, P, ws, None)
+    args = lambda C_, ws: (P, 128, C_, P, P, None, 1, 1e-5, 0.1, P, P, None, P, P, P, P, P, ws, None)
     assert fwd(*args(60, need)) == BAD_ARG                                                  # channels must come in groups of 8
     assert fwd(*args(64, need - 8)) == WORKSPACE
-    assert fwd(None, 128, 64, P, P, None, 1, 1e-5, 0.1, P, P, P, P, P, P, P, need, None) == BAD_ARG
+    assert fwd(None, 128, 64, P, P, None, 1, 1e-5, 0.1, P, P, None, P, P, P, P, P, need, None) == BAD_ARG
     assert bwd(P, P, 0, 64, P, P, P, P, 1, P, P, P, P, need, None) == BAD_ARG               # no rows
     assert bwd(P, P, 128, 64, P, P, P, P, 1, P, P, P, P, 16, None) == WORKSPACE
     assert cs(P, 128, 64, None, P, need, None) == BAD_ARG

@@ -25,7 +25,7 @@ def main(db, out):
     with gzip.open(out, "wt") as f:
         f.write("name,stream,queue,start,end,grid,wg\n")
         for r in rows:
-            n = str(r[0]).replace("void ", "").split("(")[0].replace(",", ";")
+            n = str(r[0]).replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(",", ";")
             f.write(f"{n},{r[1]},{r[2]},{r[3]},{r[4]},{r[5]},{r[6]}\n")
     print(len(rows), "dispatches ->", out)
     return 0
