@@ -24,6 +24,9 @@ cd /root/repo
 # the clock pass runs the three backbones on ONE stream: GRBM_GUI_ACTIVE is a device-wide counter, so a kernel that overlaps kernels of other streams is charged
 # their cycles too (round 3's 589 M cycles for a 0.55 ms mbconv_image launch, rows above 2.4 GHz)
 SMIRK_ENCODER_SERIAL=1 timeout 200 python tools/pmc_clock.py full $OUT/${TAG}_pmc_clock_full.txt > /dev/null 2>&1; head -24 $OUT/${TAG}_pmc_clock_full.txt 2>/dev/null | cut -c1-150
-# phase timeline of enc1_fused (variant build with -DSMIRK_DEBUG_HOOKS, made in the build container) and the co-residency microbenchmarks quoted in DESIGN.md 10.1
-if [ -f smirk_amd/lib_fz/libsmirk_hip_variant.so ]; then SMIRK_HIP_LIBRARY=/root/repo/smirk_amd/lib_fz/libsmirk_hip_variant.so timeout 120 python tools/enc1_timeline.py 1024 2>&1 | grep -v amdgpu | tee $OUT/${TAG}_enc1_timeline.txt; fi
-for m in valu_rate valu_mfma_share pool_probe; do [ -x tools/micro/$m ] && ./tools/micro/$m; done 2>&1 | tee $OUT/${TAG}_micro_valu_mfma_lds.txt | tail -12
+# kernel trace of the 128-frame shard step with the shipped defaults (one hardware queue per stream): which stream sits on which queue, when each stream starts
+cd /tmp
+rm -rf /tmp/rp_shard
+timeout 250 rocprofv3 --kernel-trace -d /tmp/rp_shard -o p -- python /root/repo/bench.py --workload full --global-batch 128 --force-collective --steps 4 --warmup 3 --no-roofline --cpu-faces 0 --traffic off > /tmp/rp_shard.log 2>&1
+db=$(find /tmp/rp_shard -name "*.db" | head -1)
+[ -n "$db" ] && python /root/repo/tools/trace_extract.py $db $OUT/${TAG}_shard128.csv.gz | tail -1 && python /root/repo/tools/step_timeline.py $OUT/${TAG}_shard128.csv.gz > $OUT/${TAG}_timeline_shard128.txt && head -22 $OUT/${TAG}_timeline_shard128.txt | cut -c1-200
