@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
 #endif
 }
 
-static int hs_env_mode() {                                           // $SMIRK_IGEMM_HALO: "0" off, "all" every eligible geometry, unset = measured default
+static int hs_env_mode() {                                           // $SMIRK_IGEMM_HALO: "0" off; unset / anything else = every eligible geometry
     const char* env = getenv("SMIRK_IGEMM_HALO");                   // read per call: tests toggle it
     return !env ? 1 : env[0] == '0' ? 0 : env[0] == 'a' ? 2 : 1;
 }
@@ -385,9 +385,11 @@ bool smirk_conv_halo_eligible(const ConvArgs& a) {
     if (a.M < 4 * HS_BM) return false;                               // tiny problems stay on the 128-row tiles
     // Measured per layer against the kernels it replaces (tools/conv_sweep.py, profiles/r03c_halo_sweep.txt): at 1024 frames per pass every deep
     // layer gains 12-18 % (14x14: 421 -> 502-513 TFLOP/s, 28x28: 405-420 -> 487-523, 56x56: 361-398 -> 431-483); at 128 frames the layers with
-    // K >= 2304 gain 3-13 % and the short-K layers (18-36 chunks per tile: the lone workgroup's prologue / epilogue are exposed) lose up to 8 %.
-    const long long tiles = ((long long)a.M + HS_BM - 1) / HS_BM * (a.N / HS_BN);
-    return mode == 2 || a.K >= 2304 || tiles >= 2048;
+    // K >= 2304 gain 3-13 % and the short-K layers (18-36 chunks per tile: the lone workgroup's prologue / epilogue are exposed) lose up to 8 % when timed
+    // ALONE.  Rounds 3-4 therefore kept short-K layers with < 2048 tiles on the 128 x 128 tiles; inside the pipeline (other streams fill what a lone
+    // workgroup per CU leaves idle) every eligible layer on this kernel measures +1.1 % at 128 frames per pass and +-0.1 % at 1024
+    // (profiles/r04x_kernel_selection.txt; round 4 had seen the same +1 % on 4 hardware queues), so the threshold is gone.
+    return true;
 }
 
 template <int NPA, int EB>
