@@ -53,6 +53,18 @@ def main():
         y64 = g64(x64)
         (y64 * w.double()).sum().backward()
         grads64 = {k: p.grad.clone() for k, p in g64.named_parameters()}
+    # BASELINE config 5 trains under bf16 autocast (train.py / config_train.yaml); the SAME class, same weights and inputs, run under
+    # torch.autocast("cpu", torch.bfloat16): its distance to the float64 arbiter is the tolerance a single-MFMA 16-bit mode of the HIP path has to meet
+    # (`refbf16_vs_64/...`; the fp32-class path is held to `ref32_vs_64/...`).  fp16 keeps 11 significand bits to bf16's 8, so such a mode sits inside it.
+    with S.reference(d) as ref:
+        gb = ref.SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+        gb.load_state_dict(sd)
+        gb.train()
+        xb = x.clone().requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            yb = gb(xb)
+        (yb.float() * w).sum().backward()
+        gradsb = {k: p.grad.clone() for k, p in gb.named_parameters()}
     # the functional restatement must be the same computation
     y2, loss2, dx2, g2, b2 = G.train_step(sd, x, w)
     assert torch.equal(y2, y.detach()), (y2 - y.detach()).abs().max()
@@ -65,11 +77,15 @@ def main():
     rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
     out["dx64"] = x64.grad.float().numpy()
     out["ref32_vs_64/dx"] = np.float64(rel(xr.grad, x64.grad))
+    out["refbf16_vs_64/dx"] = np.float64(rel(xb.grad, x64.grad))
+    out["refbf16_vs_64/y"] = np.float64(rel(yb.detach().float(), y64.detach()))
+    out["ref32_vs_64/y"] = np.float64(rel(y.detach(), y64.detach()))
     for k, v in grads64.items():
         out["gnorm64/" + k] = np.float64(v.norm().item())
         out["ghead64/" + k] = v.flatten()[:64].float().numpy()
         out["gmax64/" + k] = np.float64(v.abs().max().item())
         out["ref32_vs_64/" + k] = np.float64(rel(grads[k], v))
+        out["refbf16_vs_64/" + k] = np.float64(rel(gradsb[k], v))
         if v.numel() <= 4096:
             out["gfull64/" + k] = v.float().numpy()
     for k, v in grads.items():
@@ -82,7 +98,9 @@ def main():
             out["buf/" + k] = v.numpy()
     np.savez_compressed(os.path.join(GOLD, "generator_train_golden.npz"), **out)
     print("generator_train_golden.npz", os.path.getsize(os.path.join(GOLD, "generator_train_golden.npz")) // 1024, "KiB; loss", loss.item(),
-          "; reference fp32 vs fp64: dx", out["ref32_vs_64/dx"], "worst parameter", max(float(out["ref32_vs_64/" + k]) for k in grads))
+          "; reference fp32 vs fp64: dx", out["ref32_vs_64/dx"], "worst parameter", max(float(out["ref32_vs_64/" + k]) for k in grads),
+          "; reference under bf16 autocast vs fp64: y", out["refbf16_vs_64/y"], "dx", out["refbf16_vs_64/dx"], "median parameter",
+          float(np.median([float(out["refbf16_vs_64/" + k]) for k in grads])), "worst", max(float(out["refbf16_vs_64/" + k]) for k in grads))
 
 
 if __name__ == "__main__":

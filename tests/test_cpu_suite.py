@@ -410,3 +410,18 @@ def test_cycle_loss_formula_reproduces_the_reference_run(golden_dir):
     assert abs(loss.item() - float(g["loss64"])) < 2e-6 * float(g["loss64"])
     frozen = cycle_loss(out, {k: v.double() for k, v in feats.items()}, generator_frozen=True)       # :310-311 the shape term only without the freeze
     assert frozen.item() < loss.item()
+
+
+def test_train_golden_records_the_reference_under_bf16_autocast(golden_dir):
+    """BASELINE config 5 trains under bf16 autocast.  The train golden carries, per tensor, the distance of the REAL reference class to its own float64 run in
+    fp32 (`ref32_vs_64/*`, what the fp32-class HIP path is held to in tests/test_generator_train_gpu.py) and under torch.autocast("cpu", torch.bfloat16)
+    (`refbf16_vs_64/*`, the bound for a single-MFMA 16-bit mode).  Both sets are complete and the autocast run is orders of magnitude looser."""
+    g = np.load(os.path.join(golden_dir, "generator_train_golden.npz"))
+    k32 = {k.split("/", 1)[1] for k in g.files if k.startswith("ref32_vs_64/")}
+    k16 = {k.split("/", 1)[1] for k in g.files if k.startswith("refbf16_vs_64/")}
+    assert k32 == k16 and {"y", "dx"} <= k16 and len(k16) > 90
+    assert float(g["ref32_vs_64/y"]) < 2e-5 and float(g["refbf16_vs_64/y"]) > 1e-2                  # forward: 9e-6 vs 0.17 of the output range
+    params = sorted(k16 - {"y", "dx"})
+    med32 = float(np.median([float(g["ref32_vs_64/" + k]) for k in params]))
+    med16 = float(np.median([float(g["refbf16_vs_64/" + k]) for k in params]))
+    assert med32 < 1e-2 and med16 > 20 * med32, (med32, med16)                                        # gradients: 0.4 % vs 80 % (B = 3 BatchNorm + ReLU switching)
