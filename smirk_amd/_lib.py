@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
 ABI_VERSION = 9
+SMIRK_OK, SMIRK_ERR_BAD_ARG, SMIRK_ERR_WORKSPACE, SMIRK_ERR_LAUNCH, SMIRK_ERR_UNSUPPORTED = 0, -1, -2, -3, -4      # include/smirk_hip.h
 
 _p = C.c_void_p
 _i = C.c_int
