@@ -78,6 +78,9 @@ def parse_args(argv=None):
                          "the generator of pass i overlapping the front end of pass i+1)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="run each micro-batch strictly stage after stage (default: generator of batch i overlaps the front of batch i+1)")
+    ap.add_argument("--train-arith", choices=("f16x3", "f16x1"), default="f16x3",
+                    help="train64: arithmetic of the two CNNs' convolutions and their gradients: f16x3 = split-fp16 x3 MFMA (fp32-class, the parity mode), "
+                         "f16x1 = one fp16 MFMA per product block, the 16-bit class BASELINE config 5 names (the reference: bf16 autocast)")
     ap.add_argument("--train-graphs", dest="train_graphs", action="store_true",
                     help="train64: replay the two CNNs' forward / backward from HIP graphs instead of launching kernel by kernel (measured: host enqueue 43 -> 27 ms "
                          "per step, but the replay of ~1300 chained kernel nodes runs 3.8 ms slower on the GPU, which is the bound: 53.1 vs 49.4 ms)")
@@ -551,6 +554,8 @@ class TrainWorkload(Workload):
         self.world = world
         self.buckets = 0
         self.gen_step, self.enc_step = gen, enc
+        from smirk_amd.cycle import set_train_arith
+        set_train_arith(gen, enc, getattr(args, "train_arith", "f16x3"))
         self.graphs = bool(getattr(args, "train_graphs", False))
         self.force_collective = bool(getattr(args, "force_collective", False))
         if self.graphs:                                              # forward + backward of both CNNs as four HIP graphs (smirk_amd/cycle.py)
@@ -789,7 +794,10 @@ def main():
             "metric": METRIC[args.workload] if not args.plumbing_test else "PLUMBING TEST (CPU stub of the path; not a measurement)",
             "value": value, "unit": "faces/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": ("f32-class throughout (reference config: bf16 autocast): convolutions, their data gradients and their weight gradients as split-fp16 x3 MFMA "
+            "dtype": ("f16 products with f32 accumulate (--train-arith f16x1: one fp16 MFMA per product block on the hi halves of the split16 operands; the reference "
+                      "config trains under bf16 autocast): convolutions, their data gradients and their weight gradients; depthwise / stem weight gradients f32 VALU, "
+                      "BatchNorm statistics f64, FLAME / raster f32, Adam f32" if args.workload == "train64" and args.train_arith == "f16x1" else
+                      "f32-class throughout (reference config: bf16 autocast): convolutions, their data gradients and their weight gradients as split-fp16 x3 MFMA "
                       "with f32 accumulate (depthwise / stem weight gradients f32 VALU), BatchNorm statistics f64, FLAME / raster f32, Adam f32" if args.workload == "train64" else
                       "f32 results; encoder + generator convs as split-fp16 x3 MFMA with f32 accumulate (fp32-class error), FLAME / raster f32"
                       if gen_prec == "f16x3" or args.workload == "infer256" else "f32"),

@@ -193,6 +193,11 @@ int smirk_conv_igemm_f32(const SmirkConvDesc* d, const float* in0, const float* 
  * w is [N][K/8][2][8] halves (K ordered (ky,kx,c)), scale / shift stay fp32.  C0, C1, Cout must be multiples of 8. */
 int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
                            const float* scale, const float* shift, const void* residual, void* out, void* stream);
+/* The 16-bit class BASELINE config 5 trains in (the reference: torch.autocast(bfloat16) around smirk_trainer.py:184-332): same operands, descriptor and
+ * output format, ONE fp16 MFMA per product block (the hi halves only, fp32 accumulation).  Used by the train-mode autograd functions when a module's
+ * `train_arith` is "f16x1"; inference never calls it. */
+int smirk_conv_igemm_f16x1(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
+                           const float* scale, const float* shift, const void* residual, void* out, void* stream);
 /* The generator's tail in ONE launch (smirk_generator.py:104-113 dec1conv2+norm2+relu2, :47-49,76 conv + sigmoid): 3x3 conv (zero pad 1, stride 1,
  * split16 input, Cout = 32) + scale/shift + ReLU + 1x1 conv fw[fcout][32] + fb + sigmoid -> out_nchw[B][fcout][H][W] fp32; the 32-channel
  * activation never reaches HBM.  Returns SMIRK_ERR_UNSUPPORTED when the shape is not served by the halo-patch kernel (H, W % 16, H >= 64). */
@@ -446,6 +451,10 @@ int smirk_pack_conv_weights_batch_split16(const SmirkPackJob* jobs_device, int n
 size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout, int Cin, int KH);
 int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                          void* stream);
+/* the same weight gradient in the 16-bit class of smirk_conv_igemm_f16x1 (hi halves of dz and x, one MFMA per block, fp32 accumulation and reduction);
+ * SMIRK_ERR_UNSUPPORTED when the fp16 weight-gradient kernels do not serve the call (operands of 2 GiB and more, $SMIRK_WGRAD_F16=0). */
+int smirk_conv_wgrad_f16x1(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ---- train-mode SmirkEncoder backbones (csrc/train_encoder.hip): what `self.train()` + autograd does to the timm
  * tf_mobilenetv3_{small,large}_minimal_100 feature extractors of smirk_encoder.py:7-12 (pointwise convolutions and BatchNorm reuse the entries above).

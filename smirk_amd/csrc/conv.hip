@@ -72,7 +72,7 @@ __device__ __forceinline__ const float* psel(bool c, const float* p, const float
 enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2, KW_CMAJOR = 3, KW_LEAN = 4, KW_LEAN_CM = 5 };
 
 // one BM x BN output tile at (m0, n0); `smem` holds 2 pipeline stages of (BM + BN) x 32 dwords
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const int m0, const int n0) {
     constexpr int NW = WGM * WGN, NT = 64 * NW;                 // waves / threads per workgroup (4 or 8 waves)
     constexpr int RP = NT / 8;                                  // operand rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
@@ -318,6 +318,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     // all LDS operand reads of a chunk (both 16-k steps) go out up front into two fragment sets, then the MFMAs
     auto compute = [&](const float* As, const float* Bs) {
         if constexpr (SPLIT) {
+            if constexpr (X1) {                                   // F16X1 (its own instantiations: the three-MFMA kernels stay as they are): hi halves only
+                half8 xh[2][TM], wh[2][TN];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int pc = 2 * (2 * s + hb);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) xh[s][i] = *(const half8*)(As + lds_piece((wm * TM + i) * 32 + fr, pc));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) wh[s][j] = *(const half8*)(Bs + lds_piece((wn * TN + j) * 32 + fr, pc));
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[s][i], wh[s][j], acc[0][i][j], 0, 0, 0);
+            } else {
             half8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -343,6 +360,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                         acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[NACC - 1][i][j], 0, 0, 0);
                         acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[NACC - 1][i][j], 0, 0, 0);
                     }
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < CV_BK / 8; ++kk) {
@@ -556,28 +574,28 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
     const int ntn = (a.N + BN - 1) / BN;
     const int logical = xcd_logical(blockIdx.x, gridDim.x);
     const int mt = logical / ntn, nt = logical % ntn;
-    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK>(a, smem, mt * BM, nt * BN);
+    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK, X1>(a, smem, mt * BM, nt * BN);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false>
 static void launch_igemm_kw(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     if (g_smirk_prof_on) {                                       // the profiler's label is the instantiation that is launched HERE
         char nm[120];
-        snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d,%d,%d,%d,%s,%d>", BM, BN, WGM, WGN, SPLIT ? "true" : "false", KWALK);
+        snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d,%d,%d,%d,%s,%d>%s", BM, BN, WGM, WGN, SPLIT ? "true" : "false", KWALK, X1 ? "[f16x1]" : "");
         const double px = (double)a.d.B * a.d.H * a.d.W;
         smirk_prof_next(nm, 2.0 * a.M * a.N * a.K, 4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
     }
-    SMIRK_LAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
+    SMIRK_LAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK, X1>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SPLIT>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, bool X1 = false>
 static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     const SmirkConvDesc& d = a.d;
     // measured (B=128, same box, tap-major -> channel-major): 56x56 64->128 0.221 -> 0.201 ms, 128->128 0.367 -> 0.344, 256->128 0.725 -> 0.655;
@@ -592,8 +610,8 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
             const bool pow2 = (d.C0 & (d.C0 - 1)) == 0 && (d.C1 & (d.C1 - 1)) == 0, even = ((d.C0 + d.C1) / CV_BK) % 2 == 0;
             static const char* lcm_env = getenv("SMIRK_IGEMM_LEAN_CM");
             const bool want_cm = lcm_env ? (lcm_env[0] != '0') : (BN == 128);
-            if (want_cm && d.KH == 3 && d.KW == 3 && pow2 && even) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN_CM>(a, st);
-            else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN>(a, st);
+            if (want_cm && d.KH == 3 && d.KW == 3 && pow2 && even) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN_CM, X1>(a, st);
+            else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN, X1>(a, st);
             return;
         }
     }
@@ -601,13 +619,13 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     const bool cmajor = cm_env ? (cm_env[0] != '0') : (BN == 128 && d.Ho * d.Wo >= 400);
     if constexpr (SPLIT && WGM * WGN == 4) {
         if (cmajor && d.KH == 3 && d.KW == 3 && (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) {
-            launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_CMAJOR>(a, st);
+            launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_CMAJOR, X1>(a, st);
             return;
         }
     }
-    if ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST>(a, st);
-    else if (d.KH * d.KW == 1) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST_KT>(a, st);
-    else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC>(a, st);
+    if ((d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST, X1>(a, st);
+    else if (d.KH * d.KW == 1) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_FAST_KT, X1>(a, st);
+    else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_GENERIC, X1>(a, st);
 }
 
 // conv_pp.hip: 8-wave ping-pong kernel (256 x 128 tile, 3-stage ring) for the deep split-fp16 3x3 layers
@@ -630,7 +648,7 @@ int smirk_conv3x3_ring64_launch(const SmirkConvDesc* d, const void* in0, const v
                                 void* pooled, hipStream_t st);
 
 static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                             const float* shift, const void* residual, void* out, void* stream, bool split);
+                             const float* shift, const void* residual, void* out, void* stream, bool split, bool x1 = false);
 
 // The buffer-addressed operand DMA of the split-fp16 kernels (32-bit per-lane offsets, out-of-range rows as the zero padding) needs every
 // input tensor below 2 GiB.  A whole 1024-frame shard in one pass exceeds that on the 224^2 / 112^2 layers (6.6 / 3.3 GB): such a layer is
@@ -644,24 +662,25 @@ static int conv_batch_chunk(const SmirkConvDesc* d, bool split) {
 }
 
 static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                         const float* shift, const void* residual, void* out, void* stream, bool split) {
+                         const float* shift, const void* residual, void* out, void* stream, bool split, bool x1 = false) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
     const int bc = (d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0) ? conv_batch_chunk(d, split) : d->B;
-    if (bc >= d->B) return conv_dispatch_one(d, in0, in1, w, scale, shift, residual, out, stream, split);
+    if (bc >= d->B) return conv_dispatch_one(d, in0, in1, w, scale, shift, residual, out, stream, split, x1);
     const size_t ipx = (size_t)d->H * d->W, opx = (size_t)d->Ho * d->Wo * (d->out_mode == SMIRK_OUT_CONVT2X2 ? 4 : 1);
     for (int b0 = 0; b0 < d->B; b0 += bc) {
         SmirkConvDesc dc = *d;
         dc.B = d->B - b0 < bc ? d->B - b0 : bc;
         const int rc = conv_dispatch_one(&dc, (const float*)in0 + b0 * ipx * d->C0, in1 ? (const float*)in1 + b0 * ipx * d->C1 : nullptr, w, scale, shift,
-                                         residual ? (const float*)residual + b0 * opx * d->Cout : nullptr, (float*)out + b0 * opx * d->Cout, stream, split);
+                                         residual ? (const float*)residual + b0 * opx * d->Cout : nullptr, (float*)out + b0 * opx * d->Cout, stream, split, x1);
         if (rc != SMIRK_OK) return rc;
     }
     return SMIRK_OK;
 }
 
 static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                             const float* shift, const void* residual, void* out, void* stream, bool split) {
+                             const float* shift, const void* residual, void* out, void* stream, bool split, bool x1) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
+    if (x1 && !split) return SMIRK_ERR_BAD_ARG;
     const int cq = split ? 8 : 4;                               // channel granule: one 16-byte vector (fp32) / one hi+lo group
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->C0 <= 0 || d->C0 % cq || d->C1 % cq || d->C1 < 0 ||
         (d->C1 > 0 && !in1) || d->Ho <= 0 || d->Wo <= 0 || d->stride <= 0 || (split && d->Cout % 8))
@@ -687,13 +706,18 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
     hipStream_t st = (hipStream_t)stream;
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
-    if (split && smirk_conv3x3_ring64_eligible(d, residual != nullptr))                // conv_ring.hip: the 64-output-channel layers on large images
+    // F16X1 lives in conv_igemm_kernel only: the specialised kernels below issue the three-MFMA product unconditionally
+    if (split && !x1 && smirk_conv3x3_ring64_eligible(d, residual != nullptr))         // conv_ring.hip: the 64-output-channel layers on large images
         return smirk_conv3x3_ring64_launch(d, in0, in1, w, scale, shift, out, nullptr, st);
-    if (split && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
+    if (split && !x1 && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
-    if (split && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st);
-    if (split && smirk_conv_pp_eligible(a)) return smirk_conv_pp_launch(a, st);
-    if (split) {
+    if (split && !x1 && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st);
+    if (split && !x1 && smirk_conv_pp_eligible(a)) return smirk_conv_pp_launch(a, st);
+    if (split && x1) {                                           // F16X1: the same three tile shapes, one MFMA per block
+        if (a.N > 64) launch_igemm<128, 128, 2, 2, true, true>(a, st);
+        else if (a.N > 32) launch_igemm<128, 64, 2, 2, true, true>(a, st);
+        else launch_igemm<256, 32, 4, 1, true, true>(a, st);
+    } else if (split) {
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true>(a, st);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true>(a, st);
         else launch_igemm<256, 32, 4, 1, true>(a, st);
@@ -760,6 +784,15 @@ extern "C" int smirk_conv_igemm_f16x3(const SmirkConvDesc* d, const void* in0, c
                                       const float* scale, const float* shift, const void* residual, void* out,
                                       void* stream) {
     return conv_dispatch(d, in0, in1, w, scale, shift, residual, out, stream, true);
+}
+
+// The same convolution on the same split16 operands with ONE MFMA per product block: only the hi halves (fp16(x), 11 significand bits) enter the product,
+// accumulation stays fp32.  This is the 16-bit class of BASELINE config 5 (the reference trains under bf16 autocast: 8 significand bits); the output is
+// written split16 like every activation, so it feeds either mode.  Always conv_igemm_kernel (the three-MFMA product is compiled into the specialised kernels).
+extern "C" int smirk_conv_igemm_f16x1(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w,
+                                      const float* scale, const float* shift, const void* residual, void* out,
+                                      void* stream) {
+    return conv_dispatch(d, in0, in1, w, scale, shift, residual, out, stream, true, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -508,7 +508,7 @@ __device__ __forceinline__ half8 wgf_frag(const char* base, int off) {          
     return u.h;
 }
 
-template <int TM, int SUB>
+template <int TM, int SUB, bool X1 = false>   // X1: hi x hi only, one MFMA per block (BASELINE config 5's 16-bit class); its own instantiations
 __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trmap) {
     constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
     constexpr int BM = TM / 32 / WAVES_M, BN = 4 / WAVES_N;                 // 32 x 32 MFMA blocks per wave: 2x2 (TM 128), 2x1 (TM 64), 1x1 (TM 32)
@@ -606,16 +606,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
         for (int s = 0; s < SUB; ++s) {
             half8 ah[BM], al[BM], bh[BN], bl[BN];
 #pragma unroll
-            for (int i = 0; i < BM; ++i) { ah[i] = wgf_frag(As[buf][s], offA[i]); al[i] = wgf_frag(As[buf][s], offA[i] + AQ * 1024); }
+            for (int i = 0; i < BM; ++i) { ah[i] = wgf_frag(As[buf][s], offA[i]); if constexpr (!X1) al[i] = wgf_frag(As[buf][s], offA[i] + AQ * 1024); }
 #pragma unroll
-            for (int j = 0; j < BN; ++j) { bh[j] = wgf_frag(Bs[buf][s], offB[j]); bl[j] = wgf_frag(Bs[buf][s], offB[j] + BQ * 1024); }
+            for (int j = 0; j < BN; ++j) { bh[j] = wgf_frag(Bs[buf][s], offB[j]); if constexpr (!X1) bl[j] = wgf_frag(Bs[buf][s], offB[j] + BQ * 1024); }
 #pragma unroll
             for (int i = 0; i < BM; ++i)
 #pragma unroll
                 for (int j = 0; j < BN; ++j) {
                     acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+                    if constexpr (!X1) {
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc1[i][j], 0, 0, 0);
+                    }
                 }
         }
     }
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(WgradArgs a) {
 // pixel quads][CIN channels].  The B fragment of tap (ky, kx) for chunk pixel k is halo pixel ky*18 + kx + k: a per-lane constant added to the pixel index, so
 // the shifted fragments of all nine taps are read from the ONE staged halo (adding 4 to a pixel index moves exactly one pixel quad, hence the second transpose
 // read of an operand is again +256 bytes).  The (TM/32) x 9 x (CIN/32) MFMA blocks are dealt round-robin to NW waves; a wave's A fragments are read once per chunk.
-template <int TM, int CIN, int NW, int SUB, bool BUF>
+template <int TM, int CIN, int NW, int SUB, bool BUF, bool X1 = false>
 __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a, int trmap) {
     constexpr int NT = NW * 64, HPX = 54, HQ = 14;
     constexpr int MB = TM / 32, NBQ = CIN / 32;                               // 32-channel quads of A and B
@@ -900,17 +902,22 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
         for (int s = 0; s < SUB; ++s) {
             half8 ah[MB], al[MB];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) { ah[m] = wgf_frag(As[buf][s], offA[m]); al[m] = wgf_frag(As[buf][s], offA[m] + (GA / 4) * 1024); }
+            for (int m = 0; m < MB; ++m) { ah[m] = wgf_frag(As[buf][s], offA[m]); if constexpr (!X1) al[m] = wgf_frag(As[buf][s], offA[m] + (GA / 4) * 1024); }
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
                 const int blk = wave + NW * i;
                 if (blk < NB) {
-                    const half8 bh = wgf_frag(Bs[buf][s], offB[i]), bl = wgf_frag(Bs[buf][s], offB[i] + (GB / 4) * HQ * 256);
-                    half8 fah = ah[0], fal = al[0];
-                    if (MB == 2 && blk >= 9 * NBQ) { fah = ah[MB - 1]; fal = al[MB - 1]; }
+                    const half8 bh = wgf_frag(Bs[buf][s], offB[i]);
+                    half8 fah = ah[0];
+                    if (MB == 2 && blk >= 9 * NBQ) fah = ah[MB - 1];
                     acc0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh, acc0[i], 0, 0, 0);
-                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl, acc1[i], 0, 0, 0);
-                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh, acc1[i], 0, 0, 0);
+                    if constexpr (!X1) {
+                        const half8 bl = wgf_frag(Bs[buf][s], offB[i] + (GB / 4) * HQ * 256);
+                        half8 fal = al[0];
+                        if (MB == 2 && blk >= 9 * NBQ) fal = al[MB - 1];
+                        acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl, acc1[i], 0, 0, 0);
+                        acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh, acc1[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1172,8 +1179,20 @@ extern "C" size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout
     return (size_t)wgrad_nsplit(npix, Cout, KH * KH * Cin) * Cout * KH * KH * Cin * 4;
 }
 /* dW[Cout][(ky,kx,ci)] (fp32, the packed forward layout) = sum over pixels of dz[p][co] * x[p + tap][ci];  KH in {1, 3}, pad = (KH-1)/2 */
+static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
+                           void* stream, int x1);
 extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                                     void* stream) {
+    return conv_wgrad_impl(dz, x, dw, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 0);
+}
+/* the same weight gradient with ONE MFMA per product block (hi halves of dz and x only, fp32 accumulation): BASELINE config 5's 16-bit class.  Needs the
+ * f16 kernels (operands below 2 GiB, $SMIRK_WGRAD_F16 != 0): SMIRK_ERR_UNSUPPORTED otherwise — the caller falls back to smirk_conv_wgrad_f32 knowingly. */
+extern "C" int smirk_conv_wgrad_f16x1(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    return conv_wgrad_impl(dz, x, dw, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 1);
+}
+static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
+                           void* stream, int x1) {
     if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || Cout % 8 || Cin % 8 || Cout <= 0 || Cin <= 0 || (KH != 1 && KH != 3)) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH)) return SMIRK_ERR_WORKSPACE;
     const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
@@ -1187,9 +1206,15 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
         smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
         const bool fits32h = npix * Cout * 4 < (1ll << 31) && npix * Cin * 4 < (1ll << 31);     // 32-bit buffer offsets (see below)
         const int mode = fits32h ? wgrad_f16_mode() : 0;
+        if (x1 && !mode) return SMIRK_ERR_UNSUPPORTED;
         if (mode) {                                                          // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
             const int trmap = (mode >> 4) & 1;
-            if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 32, 3, 2, true>), dim3(nsplit), dim3(192), 0, hs, h, trmap);
+            if (x1) {
+                if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 32, 3, 2, true, true>), dim3(nsplit), dim3(192), 0, hs, h, trmap);
+                else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 32, 6, 2, false, true>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
+                else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 64, 6, 1, false, true>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
+                else SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 64, 12, 1, false, true>), dim3(nsplit), dim3(768), 0, hs, h, trmap);
+            } else if (Cout == 32 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 32, 3, 2, true>), dim3(nsplit), dim3(192), 0, hs, h, trmap);
             else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 32, 6, 2, false>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
             else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<32, 64, 6, 1, false>), dim3(nsplit), dim3(384), 0, hs, h, trmap);
             else SMIRK_LAUNCH((wgrad3x3_halo_f16_kernel<64, 64, 12, 1, false>), dim3(nsplit), dim3(768), 0, hs, h, trmap);
@@ -1212,9 +1237,14 @@ extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, in
     // the split-fp16 kernel fetches through buffer resources with 32-bit offsets: operands of 2 GiB and more take the exact-fp32 kernel (64-bit pointers)
     const bool fits32 = npix * Cout * 4 < (1ll << 31) && npix * Cin * 4 < (1ll << 31);
     const int mode = fits32 ? wgrad_f16_mode() : 0;
+    if (x1 && !mode) return SMIRK_ERR_UNSUPPORTED;
     if (mode) {                                                              // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
         const int trmap = (mode >> 4) & 1;
-        if ((mode & 15) == 1) {
+        if (x1) {                                                            // (always two chunks per barrier: the measured default)
+            if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 2, true>), grid, dim3(256), 0, st, a, trmap);
+            else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 2, true>), grid, dim3(256), 0, st, a, trmap);
+            else SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, true>), grid, dim3(256), 0, st, a, trmap);
+        } else if ((mode & 15) == 1) {
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 1>), grid, dim3(256), 0, st, a, trmap);
             else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 1>), grid, dim3(256), 0, st, a, trmap);
             else SMIRK_LAUNCH((wgrad_f16_kernel<128, 1>), grid, dim3(256), 0, st, a, trmap);

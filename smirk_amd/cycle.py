@@ -132,6 +132,20 @@ def graph_cycle_modules(generator, encoder, generator_input, encoder_input, grad
         encoder._train_serial = prev
 
 
+def set_train_arith(generator, encoder, arith):
+    """Arithmetic of the convolutions (forward, data gradient, weight gradient) of the two CNNs in TRAIN mode: "f16x3" (fp32-class, default) or "f16x1" (one
+    fp16 MFMA per product block: the 16-bit class BASELINE config 5 names; generator_train.TRAIN_ARITH).  Everything else — BatchNorm, FLAME, renderer,
+    losses, Adam — is unchanged."""
+    from .generator_train import TRAIN_ARITH
+    if arith not in TRAIN_ARITH:
+        raise ValueError(f"train_arith must be one of {TRAIN_ARITH}")
+    if generator is not None:
+        generator.train_arith = arith
+    if encoder is not None:
+        for name in ("pose_encoder", "shape_encoder", "expression_encoder"):
+            getattr(encoder, name).encoder.train_arith = arith
+
+
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20, average=True, force_collective=False):
     """Data-parallel gradient exchange (C2): flatten the gradients into few large buckets, one all-reduce each (RCCL over xGMI on GPUs, gloo in the
     CPU tests), scatter back.  Parameters without a gradient on this rank are skipped on EVERY rank only if they are skipped everywhere — the trainer

@@ -20,8 +20,8 @@ from .smirk_generator import _split16
 
 
 class _EncOps(_Ops):
-    def __init__(self, device):
-        super().__init__(device)
+    def __init__(self, device, arith="f16x3"):
+        super().__init__(device, arith=arith)
         self.dw_ws = None
         self.ones, self.zeros = {}, {}
 
@@ -80,7 +80,8 @@ class BackboneTrainFunction(torch.autograd.Function):
         B, C3, H, W = img.shape
         if C3 != 3 or H < 32 or W < 32:
             raise L.SmirkHipError("SmirkEncoder: expected [B, 3, H >= 32, W >= 32] images")
-        ops = _EncOps(img.device)
+        ctx.arith = getattr(backbone, "train_arith", "f16x3")            # generator_train.TRAIN_ARITH: "f16x1" = pointwise convs, their data and weight gradients on one MFMA
+        ops = _EncOps(img.device, arith=ctx.arith)
         lib, st = ops.lib, ops.st
         from .generator_train import PackPlan
         plan = getattr(backbone, "_pack_plan", None)                      # every pointwise weight of the backbone: one packing launch per forward
@@ -150,7 +151,7 @@ class BackboneTrainFunction(torch.autograd.Function):
         backbone, head, tape = ctx.backbone, ctx.head, ctx.tape
         ctx.plan.check_tape(ctx.plan_generation, ctx.plan_versions)
         hw_, pooled, raw, n_exp, (B, hf, wf, Cf, N) = ctx.headrec
-        ops = _EncOps(raw.device)
+        ops = _EncOps(raw.device, arith=ctx.arith)
         lib, st = ops.lib, ops.st
         grads = {}
         need = lambda p: p.requires_grad

@@ -18,6 +18,12 @@ from . import _lib as L
 from .smirk_generator import _split16, split16_to_float
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+# Arithmetic of the convolutions, their data gradients and their weight gradients in TRAIN mode, selected per module by the attribute `train_arith`:
+#   "f16x3"  split-fp16 x3 MFMA (fp32-class; the parity mode against the fp32 reference) — the default
+#   "f16x1"  the hi halves only, one MFMA per product block, fp32 accumulation: the 16-bit class BASELINE config 5 names (the reference trains under bf16
+#            autocast, base_trainer.py / train.py; fp16 keeps 11 significand bits to bf16's 8).  Activations stay split16 in memory, so the two modes
+#            share every other kernel; tested against the reference's own bf16-autocast distance to float64 (tests/golden/generator_train_golden.npz).
+TRAIN_ARITH = ("f16x3", "f16x1")
 
 
 def _pack_fwd(w, cin_pad=None):
@@ -39,9 +45,12 @@ def _pack_dgrad(w, cout_pad=None):
 class _Ops:
     """thin stateful wrapper over the C entries: one reduction workspace, the launch stream, and conv descriptors"""
 
-    def __init__(self, device, eval_bn=False):
+    def __init__(self, device, eval_bn=False, arith="f16x3"):
         self.lib, self.st, self.dev = L.lib(), L.stream_ptr(), device
         self.eval_bn = bool(eval_bn)                     # BatchNorm from the running statistics (module in .eval() inside an autograd graph)
+        if arith not in TRAIN_ARITH:
+            raise L.SmirkHipError(f"train_arith must be one of {TRAIN_ARITH}, got {arith!r}")
+        self.x1 = arith == "f16x1"                       # one MFMA per product block (hi halves only): BASELINE config 5's 16-bit class
         self.plan = None
         self.rm_saved = {}                                # eval-mode BatchNorm: id(bn) -> running_mean as the forward saw it
         self.red_ws = torch.empty(self.lib.smirk_train_reduce_workspace_bytes(1024), dtype=torch.uint8, device=device)
@@ -59,8 +68,8 @@ class _Ops:
         d.out_mode = L.OUT_CONVT2X2 if convt else L.OUT_NHWC
         out = torch.empty((B, 2 * H, 2 * W, cout) if convt else (B, d.Ho, d.Wo, cout), device=self.dev)
         P = L.ptr
-        L.check(self.lib.smirk_conv_igemm_f16x3(d, P(x0), P(x1, allow_none=True), P(w), None, P(shift, allow_none=True), P(residual, allow_none=True),
-                                                P(out), self.st))
+        entry = self.lib.smirk_conv_igemm_f16x1 if self.x1 else self.lib.smirk_conv_igemm_f16x3
+        L.check(entry(d, P(x0), P(x1, allow_none=True), P(w), None, P(shift, allow_none=True), P(residual, allow_none=True), P(out), self.st))
         return out
 
     def pack(self, weight, cin_off=0, cin=None, cin_pad=None, fwd=True, dgrad=True):
@@ -134,7 +143,11 @@ class _Ops:
             self.wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         dw = torch.empty(cout, k * k * cin, device=self.dev)
         P = L.ptr
-        L.check(self.lib.smirk_conv_wgrad_f32(P(dz), P(x), P(dw), B, H, W, cout, cin, k, int(reflect), P(self.wg_ws, torch.uint8), self.wg_ws.numel(), self.st))
+        args = (P(dz), P(x), P(dw), B, H, W, cout, cin, k, int(reflect), P(self.wg_ws, torch.uint8), self.wg_ws.numel(), self.st)
+        rc = self.lib.smirk_conv_wgrad_f16x1(*args) if self.x1 else L.SMIRK_ERR_UNSUPPORTED
+        if rc == L.SMIRK_ERR_UNSUPPORTED:                # (f16x1 needs the fp16 weight-gradient kernels: operands >= 2 GiB take the exact-fp32 kernel)
+            rc = self.lib.smirk_conv_wgrad_f32(*args)
+        L.check(rc)
         return dw
 
     def colsum(self, x):
@@ -226,7 +239,8 @@ class GeneratorTrainFunction(torch.autograd.Function):
             raise L.SmirkHipError("SmirkGenerator: expected [B, in_channels, H, W] with H, W multiples of 16")
         if module.features % 8 or module.in_channels > 8:
             raise L.SmirkHipError("training runs in the split-fp16 mode: init_features % 8 == 0 and in_channels <= 8")
-        ops = _Ops(x.device, eval_bn=not module.training)
+        ctx.arith = getattr(module, "train_arith", "f16x3")
+        ops = _Ops(x.device, eval_bn=not module.training, arith=ctx.arith)
         lib, st, f = ops.lib, ops.st, module.features
         ctx.eval_bn = not module.training
         plan = getattr(module, "_pack_plan", None)
@@ -310,7 +324,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
         B, Cx, H, W = ctx.shape
         f = module.features
         ctx.plan.check_tape(ctx.plan_generation, ctx.plan_versions)
-        ops = _Ops(y.device, eval_bn=ctx.eval_bn)
+        ops = _Ops(y.device, eval_bn=ctx.eval_bn, arith=ctx.arith)
         ops.rm_saved = ctx.rm_saved
         lib, st = ops.lib, ops.st
         grads = {}                                                        # id(parameter) -> gradient in the parameter's layout

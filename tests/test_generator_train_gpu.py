@@ -241,3 +241,47 @@ def test_stale_tape_after_weight_update_and_another_forward_raises_like_autograd
         yd.sum().backward()
     ye.sum().backward()
     assert torch.isfinite(xe.grad).all()
+
+
+def test_train_step_f16x1_is_inside_the_reference_bf16_autocast_distance(golden_dir):
+    """`train_arith = "f16x1"` (one fp16 MFMA per product block: BASELINE config 5's 16-bit class).  The bound is the REAL reference class under
+    torch.autocast('cpu', torch.bfloat16) measured against its own float64 run on the golden's inputs (`refbf16_vs_64/*`, oracle/make_train_golden.py): every
+    tensor of the HIP step is at least as close to float64 as that, the forward by a wide margin (11 significand bits against 8).  Running statistics and the
+    step counter behave as in the default arithmetic; an unknown arithmetic name is refused."""
+    g = np.load(os.path.join(golden_dir, "generator_train_golden.npz"))
+    sd = G.synth_state_dict()
+    x, w = MT.inputs()
+    m = _module(sd)
+    m.train_arith = "f16x1"
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    ey = (y.detach().cpu().double() - torch.from_numpy(g["y"]).double()).abs().max().item() / float(np.abs(g["y"]).max())
+    assert ey < 0.25 * float(g["refbf16_vs_64/y"]), ey                    # measured 0.025 against the reference's 0.166 under bf16 autocast
+    (y * w.cuda()).sum().backward()
+    e_dx = _rel(xg.grad.cpu(), torch.from_numpy(g["dx64"]))
+    assert e_dx <= float(g["refbf16_vs_64/dx"]), e_dx
+    errs, over = {}, []
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        gmax = float(g["gmax64/" + k])
+        e = (p.grad.flatten()[:64].cpu() - torch.from_numpy(g["ghead64/" + k])).abs().max().item() / max(gmax, 1e-12)
+        if "gfull64/" + k in g.files:
+            e = max(e, (p.grad.cpu() - torch.from_numpy(g["gfull64/" + k])).abs().max().item() / max(gmax, 1e-12))
+        errs[k] = e
+        if e > float(g["refbf16_vs_64/" + k]):
+            over.append((k, e, float(g["refbf16_vs_64/" + k])))
+    med = float(np.median(list(errs.values())))
+    ref_med = float(np.median([float(g["refbf16_vs_64/" + k]) for k in errs]))
+    print(f"f16x1 vs float64: y {ey:.2e} (reference bf16 autocast {float(g['refbf16_vs_64/y']):.2e}); dx {e_dx:.2e} ({float(g['refbf16_vs_64/dx']):.2e}); "
+          f"parameters median {med:.2e} max {max(errs.values()):.2e} (reference bf16 autocast: median {ref_med:.2e})")
+    assert not over, over[:5]
+    assert med < 0.5 * ref_med
+    for k, b in m.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            ref = torch.from_numpy(g["buf/" + k])
+            assert (b.cpu() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item()), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(b) == 1, k
+    m.train_arith = "bf16"
+    with pytest.raises(Exception, match="train_arith"):
+        m(x.cuda())

@@ -394,3 +394,49 @@ def test_batchnorm_train_is_deterministic():
         runs.append([t.clone() for t in (y, mean, inv, dz, dg, db)])
     for r in runs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+
+
+# ---- F16X1: BASELINE config 5's 16-bit class (one MFMA per product block, the hi halves only) -----------------------------------------------------------------------
+def _hi64(s, nchw=True):
+    """the fp16 hi halves of a split16 NHWC tensor as float64 (what the F16X1 kernels multiply)"""
+    B, H, W, C = s.shape
+    hi = s.reshape(B, H, W, C // 8, 8).view(torch.float16).reshape(B, H, W, C // 8, 2, 8)[..., 0, :].reshape(B, H, W, C)
+    hi = hi.cpu().double()
+    return hi.permute(0, 3, 1, 2).contiguous() if nchw else hi
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [(2, 16, 16, 32, 64, 3), (1, 32, 32, 64, 32, 3), (2, 14, 14, 512, 512, 3), (3, 7, 7, 40, 120, 1), (1, 56, 56, 128, 128, 3),
+                                                (2, 28, 28, 256, 24, 1)])
+def test_conv_f16x1_is_the_fp16_rounded_product_with_f32_accumulation(B, H, W, cin, cout, k):
+    """smirk_conv_igemm_f16x1 == conv2d(fp16(x), fp16(w)) accumulated in fp32: exact semantics, so the bound is fp32 round-off — and it differs from the
+    x3 result by the 2^-11 the lo halves carry (the two entries are not accidentally the same kernel)"""
+    T, _ = _ops()
+    o1, o3 = T._Ops(torch.device("cuda"), arith="f16x1"), T._Ops(torch.device("cuda"))
+    g = _gen(cin + cout + k)
+    xs, _ = _act(torch.randn(B, H, W, cin, generator=g))
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    from smirk_amd.smirk_generator import _split16
+    wp = _split16(wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda())
+    got1, got3 = o1.conv(xs, None, wp, B, H, W, cout, k=k), o3.conv(xs, None, wp, B, H, W, cout, k=k)
+    w_hi = wp.reshape(cout, -1).view(torch.float16).reshape(cout, -1, 2, 8)[:, :, 0, :].reshape(cout, k, k, cin).permute(0, 3, 1, 2).cpu().double()
+    ref = F.conv2d(_hi64(xs), w_hi, padding=(k - 1) // 2)
+    assert _rel(_val(got1), ref) < TOL
+    d13 = _rel(_val(got1), _val(got3))
+    assert 2e-5 < d13 < 3e-3, d13
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,reflect", [(2, 8, 8, 32, 64, 3, False), (2, 4, 4, 512, 512, 3, True), (2, 16, 16, 32, 32, 3, False), (1, 32, 16, 64, 64, 3, False),
+                                                        (3, 7, 7, 40, 120, 1, False), (2, 112, 112, 64, 64, 3, False)])
+def test_conv_weight_gradient_f16x1(B, H, W, cin, cout, k, reflect):
+    """smirk_conv_wgrad_f16x1 (generic split-K tiles and the all-taps halo kernels) == autograd's weight gradient of the fp16-rounded operands"""
+    T, _ = _ops()
+    o1 = T._Ops(torch.device("cuda"), arith="f16x1")
+    g = _gen(H * cin + cout + 1)
+    xs, _ = _act(torch.randn(B, H, W, cin, generator=g))
+    ds, _ = _act(torch.randn(B, H, W, cout, generator=g))
+    dw = o1.wgrad(ds, xs, B, H, W, cout, cin, k, reflect=reflect)
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    x64, d64 = _hi64(xs), _hi64(ds)
+    xin = F.pad(x64, (1, 1, 1, 1), mode="reflect") if reflect else x64
+    F.conv2d(xin, w, padding=0 if (reflect or k == 1) else 1).backward(d64)
+    assert _rel(T._to_conv_weight_grad(dw, cout, cin, k).cpu(), w.grad) < TOL
