@@ -98,6 +98,9 @@ def parse_args(argv=None):
     ap.add_argument("--traffic", choices=("measure", "file", "off"), default=None,
                     help="roofline.traffic: run two rocprofv3 --pmc passes of this script (default at 1 GPU), read profiles/pmc_traffic.json, or skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default `full` run on one GPU: skip the short timed regions of the other BASELINE configs that are reported under \"also\" "
+                         "(flame512, infer256, train64 in both arithmetics, the 128-frame shard of the 8-GPU job with the RCCL gather enqueued)")
     ap.add_argument("--flame-basis", choices=("random", "smooth"), default="random",
                     help="synthetic FLAME blendshape basis: 'random' = SURVEY.md 8(d) (i.i.d. directions: ~21 x 22-pixel triangle boxes); 'smooth' = low-frequency "
                          "fields like a real shape model (~4-pixel triangles) - only the rasteriser's share of the step changes")
@@ -354,6 +357,25 @@ def measure_traffic(args):
         wn, ws = w.get(k, (1, 0.0))
         table[k] = {"launches": n, "fetch_kb": s / n, "write_kb": ws / max(wn, 1), "bytes_per_launch": (2 * s / n + ws / max(wn, 1)) * 1024}
     return table
+
+
+def rocprofv3_avg(workload, kernel):
+    """rocprofv3 --kernel-trace --stats' own per-launch average of `kernel` for this workload's command line, from the committed summary of the SAME kernel
+    sources (tools/rocprof_summary.py writes the JSON); None-with-reason otherwise."""
+    f = os.path.join(REPO, "profiles", f"rocprofv3_kernel_avg_{workload}.json")
+    try:
+        j = json.load(open(f))
+    except Exception:                       # noqa: BLE001
+        return {"avg_launch_us": None, "why": f"no profiles/rocprofv3_kernel_avg_{workload}.json"}
+    if j.get("kernel_sources_sha") != kernel_sources_sha():
+        return {"avg_launch_us": None, "why": "profiles/rocprofv3_kernel_avg_%s.json was taken on other kernel sources (sha %s)" % (workload, j.get("kernel_sources_sha"))}
+    key = kernel.split("[")[0].replace(", ", ",")
+    k = j["kernels"].get(key)
+    if k is None:
+        return {"avg_launch_us": None, "why": f"{key} not in {os.path.basename(f)}"}
+    return {"avg_launch_us": k["avg_us"], "calls": k["calls"], "command": j.get("command"), "file": "profiles/" + str(j.get("summary_file")),
+            "kernel_sources_sha": j["kernel_sources_sha"],
+            "note": "rocprofv3's average over the timed-region schedule (two half-batch chains in the deep section, generator overlapping the next pass's front end)"}
 
 
 def per_rank_batch(args, world):
@@ -648,19 +670,110 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
                 "note": ("achieved = ALGORITHMIC 2*M*N*K flop per launch / HIP-event launch time; the split-fp16 kernel issues 3 fp16 MFMAs per product "
                          "(hi.hi, hi.lo, lo.hi), so its matrix-pipe occupancy is mfma_issue_frac; peak = dense fp16 MFMA at the nominal 2.4 GHz - a separate "
                          "GRBM_GUI_ACTIVE pass (tools/pmc_clock.py, profiles/r03u_pmc_clock_full.txt, round 3; not re-measured by this run) found the deep-layer kernel "
-                         "running at 1.62 GHz under the power cap with its matrix pipe 0.81 busy at that clock") if split else
+                         "running at 1.62 GHz under the power cap with its matrix pipe 0.81 busy at that clock.  launches_per_pass / avg_launch_ms / flop_per_launch "
+                         "describe the INSTRUMENTED pass, which runs the generator's deep section (H/8 and H/16 layers) as ONE whole-batch chain because the launch "
+                         "profiler times launches on one stream; the TIMED region runs that section as two half-batch chains on two streams (csrc/network.hip), "
+                         "i.e. twice as many launches of half the flop each, overlapping each other and the next pass's front end - `rocprofv3` below is the "
+                         "per-launch average of that state") if split else
                         "achieved = algorithmic flop per launch / HIP-event launch time; peak = f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
     else:
         roof = {"bound": "hbm", "kernel": dom, "achieved": by / tm / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by / tm / PEAK_HBM,
                 "traffic": traffic, "bytes_per_launch": by / n,
                 "note": "achieved = algorithmic bytes (unique operands in + out) per launch / HIP-event launch time" if by else
                         "the dispatcher states no algorithmic byte count for this kernel"}
+    roof["rocprofv3"] = rocprofv3_avg(workload, dom)
     roof.update(launches_per_pass=n, avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
                 kernel_name_source="libsmirk_hip.so launch profiler (smirk_profile_start/stop): the instantiation that was launched, HIP events on its launch stream",
                 kernels={k: {"ms_per_pass": round(v[2] * 1e3, 4), "launches": v[3], **({"tflops": round(v[0] / v[2] / 1e12, 2)} if v[0] > 0 else {}),
                              **({"gbps": round(v[1] / v[2] / 1e9, 1)} if v[1] > 0 else {})} for k, v in sorted(per.items(), key=lambda t: -t[1][2])[:28]},
                 profiled_kernel_ms_per_pass=sum(v[2] for v in per.values()) * 1e3, wall_ms_per_pass=dt_pass * 1e3)
     return roof
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# "also": the other BASELINE configs, timed in the same process AFTER the headline's timed region (the driver only ever runs `bench.py --gpus 1`)
+# ------------------------------------------------------------------------------------------------------------------------------
+ALSO_SPECS = (   # name, argv overrides, steps, warmup
+    ("flame512", dict(workload="flame512"), 50, 10),
+    ("infer256", dict(workload="infer256"), 10, 3),
+    ("train64_f16x3", dict(workload="train64", train_arith="f16x3"), 6, 3),
+    ("train64_f16x1", dict(workload="train64", train_arith="f16x1"), 6, 3),
+    ("full_shard128_collective", dict(workload="full", global_batch=128, force_collective=True), 10, 3),
+)
+
+
+def run_also(args, dev, L):
+    """Short timed regions of BASELINE configs 2, 3, 5 (both training arithmetics) and of the per-rank shard of the 8-GPU job (128 frames, the asynchronous
+    all-gather really enqueued through a world-size-1 RCCL group).  Same step()/drain()/synchronize bracketing as the headline, same workload classes as
+    `--workload X`; each entry carries the roofline fraction of ITS dominant kernel (launch profiler, one instrumented pass; no counter passes).  Runs after
+    the headline's timed region and touches none of its fields; an entry that fails reports its error instead of taking the line down."""
+    import copy
+    import gc
+    import torch
+    import torch.distributed as dist
+    out, t_all = {}, time.perf_counter()
+    cache = {}
+    for name, over, steps, warmup in ALSO_SPECS:
+        t_entry = time.perf_counter()
+        a = copy.copy(args)
+        a.global_batch = a.batch = None
+        a.force_collective = False
+        a.micro_batch = MICRO_BATCH
+        for k, v in over.items():
+            setattr(a, k, v)
+        own_group, wl = False, None
+        try:
+            if a.force_collective and not dist.is_initialized():
+                s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+                dist.init_process_group(a.backend, init_method=f"tcp://127.0.0.1:{port_}", rank=0, world_size=1, device_id=dev)
+                own_group = True
+            sb = tempfile.mkdtemp(prefix=f"smirk_also_{name}_")
+            if a.workload == "train64" and "train64" in cache:          # the second arithmetic re-uses the modules, inputs and optimiser state
+                wl = cache["train64"]
+                from smirk_amd.cycle import set_train_arith
+                set_train_arith(wl.gen, wl.enc, a.train_arith)
+            else:
+                cls = {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload, "train64": TrainWorkload}[a.workload]
+                wl = cls(a, dev, 0, 1, sb)
+                if a.workload == "train64":
+                    cache["train64"] = wl
+            for _ in range(warmup):
+                wl.step()
+            wl.drain(); torch.cuda.synchronize()
+            assert_finite(wl.last, wl.keys, f"also/{name} after warm-up")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wl.step()
+            wl.drain(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert_finite(wl.last, wl.keys, f"also/{name} after the timed steps")
+            L.profile_start()
+            wl.instrumented(); wl.drain(); torch.cuda.synchronize()
+            recs = L.profile_stop()
+            roof = roofline_from_records(recs, a.workload, None, "not collected (also-entry)", dt / steps)
+            e = {"metric": METRIC[a.workload], "value": wl.B * steps / dt, "unit": "faces/sec", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                 "frames_per_step": wl.B,
+                 "dtype": ("f16 products, f32 accumulate (one fp16 MFMA per product block)" if over.get("train_arith") == "f16x1" else
+                           "f32 (fp32 MFMA)" if a.workload == "flame512" else "f32-class (split-fp16 x3 MFMA, f32 accumulate)"),
+                 "launches_per_step": len(recs)}
+            if roof is not None:
+                e["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_pass", "avg_launch_ms",
+                                                          "profiled_kernel_ms_per_pass")}
+            if a.workload == "train64":
+                e["loss"] = float(wl.last["loss"])
+            out[name] = e
+        except Exception as ex:                     # noqa: BLE001 — the headline line must still be produced
+            out[name] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
+        finally:
+            if own_group and dist.is_initialized():
+                dist.destroy_process_group()
+            if a.workload != "train64":
+                wl = None
+            gc.collect(); torch.cuda.empty_cache()
+        out[name]["wall_s"] = round(time.perf_counter() - t_entry, 2)
+    cache.clear(); gc.collect(); torch.cuda.empty_cache()
+    out["_note"] = ("timed in this process after the headline's timed region, inputs resident, same step/drain/synchronize bracketing; builder-side full-length "
+                    "lines of the same workloads are under profiles/; total wall %.1f s" % (time.perf_counter() - t_all))
+    return out
 
 
 def main():
@@ -735,6 +848,15 @@ def main():
     if wl.last is not None and not args.plumbing_test:
         assert_finite(wl.last, wl.keys, "after the timed steps")
         stats = output_stats(wl.last)
+    # host time to enqueue ONE step into an EMPTY launch queue (after the synchronisation above, outside the timed region).  Over the K back-to-back steps of
+    # the timed region the launch queue fills and the host blocks on it, so t_host / K measures back-pressure, not enqueue cost (round 4: 33.9 ms in the
+    # driver's 20-step run against 2.2 ms in a 5-step run of the same code); both are reported, under names that say which is which.
+    t_enq1 = None
+    if not args.plumbing_test and not args.pmc_inner:
+        te = time.perf_counter()
+        wl.step()
+        t_enq1 = time.perf_counter() - te
+        wl.drain(); sync()
 
     roof = None
     if rank == 0 and not args.no_roofline and not args.plumbing_test:
@@ -780,6 +902,15 @@ def main():
                                        "note": "the dominant kernel while the generator of one pass overlaps encode + FLAME + render of the next (the timed region's steady "
                                                "state; rocprofv3's per-kernel average of this command is taken in this state); `achieved` / `frac` above are the kernel alone"}
 
+    also = None
+    if (rank == 0 and world == 1 and args.workload == "full" and not args.no_also and not args.plumbing_test and args.global_batch is None
+            and args.batch is None and not args.force_collective):
+        B_headline, gen_prec_headline = wl.B, getattr(getattr(wl, "gen", None), "precision", None)
+        wl_keep = type("Done", (), {"B": B_headline, "gen": type("G", (), {"precision": gen_prec_headline})(), "buckets": 0, "graphs": False})()
+        wl = wl_keep                          # release the headline's modules and its ~64 GB of activations before the other configs run
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        also = run_also(args, dev, L)
     if rank == 0:
         B = wl.B
         faces = B * world * args.steps
@@ -828,10 +959,13 @@ def main():
                                         "backbones of batch i+1)" if args.infer_lanes > 1 else "one batch at a time")}
                           if args.workload == "infer256" else {}),
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
-            "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+            "host_enqueue_ms_one_step_idle_queue": (t_enq1 * 1e3 if t_enq1 is not None else None),
+            "host_submit_ms_per_step_incl_queue_backpressure": t_host / args.steps * 1e3,
             "path_tflops_per_gpu": value / world * flop_face / 1e12,
             "path_frac_of_f16_mfma_peak": value / world * flop_face / PEAK_F16_MFMA,
             "output_stats": stats, "roofline": roof, "cpu_baseline": cpu}
+        if also is not None:
+            line["also"] = also
         if args.plumbing_test:
             line["plumbing"] = {"gathered_ids_last": wl.seen[-1], "micro_batches_per_step": len(wl.slices), "gathers": len(wl.seen)}
         try:                                 # RCCL prints its version banner through C stdio: flush it out BEFORE the JSON line, which stays the last line on stdout
