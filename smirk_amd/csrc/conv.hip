@@ -601,22 +601,19 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st) {
     // measured (B=128, same box, tap-major -> channel-major): 56x56 64->128 0.221 -> 0.201 ms, 128->128 0.367 -> 0.344, 256->128 0.725 -> 0.655;
     // 28x28 128->256 0.203 -> 0.184, 256->256 0.357 -> 0.336, 512->256 0.680 -> 0.652; 14x14 layers unchanged; 112x112 64->64 (128x64 tile) 0.51 -> 0.54
     // default ON (measured, B=128, same box, old paths -> lean: 14x14x512 0.346 -> 0.327 ms, 28x28 512->256 0.665 -> 0.590, 56x56 256->128
-    // 0.715 -> 0.605, 112x112 64->64 0.50 -> 0.46); SMIRK_IGEMM_LEAN=0 restores the pointer-based K walks
-    static const char* lean_env = getenv("SMIRK_IGEMM_LEAN");
-    const bool lean = !(lean_env && lean_env[0] == '0');
+    // 0.715 -> 0.605, 112x112 64->64 0.50 -> 0.46); the pointer-based K walks below remain for operands the 32-bit buffer offsets cannot address
+    const bool lean = true;
     if constexpr (SPLIT && WGM * WGN == 4) {
         const long long b0 = (long long)d.B * d.H * d.W * d.C0 * 4, b1 = (long long)d.B * d.H * d.W * d.C1 * 4, bw = (long long)a.N * a.K * 4;
         if (lean && (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0) && b0 < (1ll << 31) && b1 < (1ll << 31) && bw < (1ll << 31)) {
             const bool pow2 = (d.C0 & (d.C0 - 1)) == 0 && (d.C1 & (d.C1 - 1)) == 0, even = ((d.C0 + d.C1) / CV_BK) % 2 == 0;
-            static const char* lcm_env = getenv("SMIRK_IGEMM_LEAN_CM");
-            const bool want_cm = lcm_env ? (lcm_env[0] != '0') : (BN == 128);
+            const bool want_cm = BN == 128;        // (the 128 x 64 tile keeps the tap-major lean walk: DESIGN.md section 6, the channel-major instantiation of that tile)
             if (want_cm && d.KH == 3 && d.KW == 3 && pow2 && even) launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN_CM, X1>(a, st);
             else launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_LEAN, X1>(a, st);
             return;
         }
     }
-    static const char* cm_env = getenv("SMIRK_IGEMM_CMAJOR");    // "0" forces tap-major, "1" forces channel-major everywhere it applies
-    const bool cmajor = cm_env ? (cm_env[0] != '0') : (BN == 128 && d.Ho * d.Wo >= 400);
+    const bool cmajor = BN == 128 && d.Ho * d.Wo >= 400;
     if constexpr (SPLIT && WGM * WGN == 4) {
         if (cmajor && d.KH == 3 && d.KW == 3 && (d.C0 % CV_BK == 0) && (d.C1 % CV_BK == 0)) {
             launch_igemm_kw<BM, BN, WGM, WGN, SPLIT, KW_CMAJOR, X1>(a, st);
@@ -705,9 +702,9 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
     if (d->KH == 3)                                             // only convs with a halo profit from patch ordering
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
     hipStream_t st = (hipStream_t)stream;
-    static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests
+    static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests: neither the patch nor the ring kernels
     // F16X1 lives in conv_igemm_kernel only: the specialised kernels below issue the three-MFMA product unconditionally
-    if (split && !x1 && smirk_conv3x3_ring64_eligible(d, residual != nullptr))         // conv_ring.hip: the 64-output-channel layers on large images
+    if (split && !x1 && !no_patch && smirk_conv3x3_ring64_eligible(d, residual != nullptr))         // conv_ring.hip: the 64-output-channel layers on large images
         return smirk_conv3x3_ring64_launch(d, in0, in1, w, scale, shift, out, nullptr, st);
     if (split && !x1 && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);

@@ -425,18 +425,7 @@ int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
-    const char* ebe = getenv("SMIRK_HALO_EB");                       // tuning switch: MFMAs issued after the hand-over barrier (0, 4, 8)
-    const int eb = ebe ? atoi(ebe) : HS_DEFAULT_EB;
-    if (npa <= 5) {
-        switch (eb) {
-            case 0: return hs_launch<5, 0>(a, st, lds, dev);
-            case 8: return hs_launch<5, 8>(a, st, lds, dev);
-            default: return hs_launch<5, 4>(a, st, lds, dev);
-        }
-    }
-    switch (eb) {
-        case 0: return hs_launch<6, 0>(a, st, lds, dev);
-        case 8: return hs_launch<6, 8>(a, st, lds, dev);
-        default: return hs_launch<6, 4>(a, st, lds, dev);
-    }
+    // (EB = MFMAs issued after the hand-over barrier: 4 / 8 measured 3-7 % slower without the time stamps in, profiles/r03b_halo_nl_sweep.txt, r04x_kernel_selection.txt;
+    // the $SMIRK_HALO_EB switch and its instantiations left the library in round 5)
+    return npa <= 5 ? hs_launch<5, HS_DEFAULT_EB>(a, st, lds, dev) : hs_launch<6, HS_DEFAULT_EB>(a, st, lds, dev);
 }

@@ -659,7 +659,7 @@ static bool patch_resident(const SmirkConvDesc* d) {             // whole weight
 }
 static bool patch_streamed(const SmirkConvDesc* d) {             // Cout = 64, whole 32-channel chunks: weights streamed per half-chunk
     // measured (B=128, 112x112): 128->64 0.90 ms vs 1.02 ms on the implicit-GEMM kernel, 64->64 0.53 vs 0.50 ms => only for >= 4 chunks
-    return d->Cout == 64 && d->C0 % 32 == 0 && d->C1 % 32 == 0 && (d->C0 + d->C1) >= 128 && getenv("SMIRK_DISABLE_PATCH_STREAM") == nullptr;
+    return d->Cout == 64 && d->C0 % 32 == 0 && d->C1 % 32 == 0 && (d->C0 + d->C1) >= 128;
 }
 static bool patch_eligible(const SmirkConvDesc* d, bool has_residual) {
     return patch_common(d, has_residual) && (patch_resident(d) || patch_streamed(d));
@@ -683,10 +683,9 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
     a.nchunk = (d->C0 + 31) / 32 + (d->C1 + 31) / 32;
     a.npatch = d->B * (d->H / PT) * (d->W / PT);
     {
-        static const char* nb = getenv("SMIRK_PATCH_NO_BUFFER_DMA");
         const long long px = (long long)d->B * d->H * d->W;
         const bool pow2 = (d->C0 & (d->C0 - 1)) == 0 && (d->C1 & (d->C1 - 1)) == 0;
-        a.use_buf = (!nb && pow2 && px * d->C0 * 4 < (1ll << 31) && px * d->C1 * 4 < (1ll << 31)) ? 1 : 0;
+        a.use_buf = (pow2 && px * d->C0 * 4 < (1ll << 31) && px * d->C1 * 4 < (1ll << 31)) ? 1 : 0;
     }
     if (g_smirk_prof_on) {
         const double px = (double)d->B * d->H * d->W, K = 9.0 * (d->C0 + d->C1);
@@ -713,44 +712,16 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<2, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 3, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 3, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<1, 1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     // (round 4: two 4-wave groups sharing the weights on 16 x 16 patches, <1,1,16,2> with the LDS-counter group barrier: dec1a 7.38 -> 10.72 ms — removed again)
-    // three-stage ring variants (Cout = 32), opt-in for A/B: SMIRK_PATCH_RING=8 (16 x 8 patches) / =16 (16 x 16 patches, single-chunk layers only).
-    // Measured (B = 128, 224^2, 32 -> 32): ring of 16 x 8 patches 0.84 ms vs 0.54 ms for two single-stage workgroups per CU — a lone 4-wave
-    // workgroup with ONE M tile per wave has two accumulator chains per wave and nothing else on its SIMD: MFMA latency, not DMA latency, decides.
-    constexpr size_t PSTG8 = (size_t)(((8 + 2) * PH + 7) / 8 * 8) * 32 * 4;
-    const char* ring_env = getenv("SMIRK_PATCH_RING");
-    const int ring = ring_env ? atoi(ring_env) : 0;
-    if (ring == 8 && d->Cout == 32 && d->H % 8 == 0 && wbytes + 3 * PSTG8 <= 160 * 1024) {
-        a.npatch = d->B * (d->H / 8) * (d->W / PT);
-        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 3, 8, 1>), dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), wbytes + 3 * PSTG8, st, a);
-        return smirk_launch_status();
-    }
-    if (ring == 28 && d->Cout == 32 && d->H % 8 == 0 && 256 + wbytes + 4 * PSTG8 <= 160 * 1024) {          // two groups x two stages of 16 x 8 patches
-        a.npatch = d->B * (d->H / 8) * (d->W / PT);
-        const int g2 = (a.npatch + 1) / 2;
-        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2, 8, 2>), dim3(g2 < 256 ? g2 : 256), dim3(512), 256 + wbytes + 4 * PSTG8, st, a);
-        return smirk_launch_status();
-    }
-    if ((ring == 28 || ring == 18) && d->Cout == 32 && d->H % 8 == 0 && 256 + wbytes + 2 * PSTG8 <= 160 * 1024) {   // two groups x one stage (two-chunk layers)
-        a.npatch = d->B * (d->H / 8) * (d->W / PT);
-        const int g2 = (a.npatch + 1) / 2;
-        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1, 8, 2>), dim3(g2 < 256 ? g2 : 256), dim3(512), 256 + wbytes + 2 * PSTG8, st, a);
-        return smirk_launch_status();
-    }
-    if (ring == 16 && d->Cout == 32 && wbytes + 3 * (size_t)PSTAGE * 4 <= 160 * 1024) {
-        SMIRK_LAUNCH((conv3x3_patch_kernel<1, 3, 16, 1>), dim3(a.npatch < 256 ? a.npatch : 256), dim3(256), wbytes + 3 * (size_t)PSTAGE * 4, st, a);
-        return smirk_launch_status();
-    }
-    const bool one_stage = (wbytes + (size_t)PSTAGE * 4) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
-    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4 + (fout ? (4 * 32 + 4) * 4 : 0);      // + the fused tail's 1x1 weights / biases
-    static const char* cap_env = getenv("SMIRK_PATCH_CAP");
-    const int cap = cap_env ? atoi(cap_env) : (one_stage ? 512 : 256);
+    // (rounds 2-4 kept three-stage-ring and two-group variants of this kernel behind $SMIRK_PATCH_RING: all measured 15-50 % slower than two single-stage workgroups
+    // per CU — a lone 4-wave workgroup with one M tile per wave has two accumulator chains per wave and nothing else on its SIMD, so MFMA latency, not DMA latency,
+    // decides (profiles/r02_patch_timeline_and_variants.txt) — and left the library in round 5 together with the switch.)
+    const size_t tail = fout ? (4 * 32 + 4) * 4 : 0;                                              // the fused tail's 1x1 weights / biases
+    const bool one_stage = (wbytes + (size_t)PSTAGE * 4 + tail) * 2 <= 160 * 1024 && d->Cout == 32;    // two workgroups per CU fit
+    const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4 + tail;
+    const int cap = one_stage ? 512 : 256;
     const int grid = a.npatch < cap ? a.npatch : cap;
     if (d->Cout == 32 && one_stage) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1, 16, 1>), dim3(grid), dim3(256), lds, st, a);
     else if (d->Cout == 32) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2, 16, 1>), dim3(grid), dim3(256), lds, st, a);

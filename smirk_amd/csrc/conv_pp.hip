@@ -336,10 +336,7 @@ int smirk_conv_pp_launch(const ConvArgs& a_in, hipStream_t st) {
     if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
     bool& attr_done = attr_done_dev[dev];
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv_pp_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES) != hipSuccess)
             return SMIRK_ERR_LAUNCH;
         attr_done = true;
     }
@@ -347,19 +344,14 @@ int smirk_conv_pp_launch(const ConvArgs& a_in, hipStream_t st) {
 #ifdef SMIRK_DEBUG_HOOKS                                                 /* -DSMIRK_DEBUG_HOOKS variant builds only (tools/build_variant.sh) */
     if (const char* ab = getenv("SMIRK_PP_ABLATE")) a.ablate = atoi(ab);        // WRONG RESULTS: operand-traffic timing experiments
 #endif
-    const char* nle = getenv("SMIRK_PP_NL");                         // tuning switch: DMA instructions issued in the load phase (default 3)
-    const int nl = nle ? atoi(nle) : 3;
+    // NL = 3 of a wave's 6 LDS-DMA instructions per chunk are issued in its load phase, 3 among the MFMAs.  0 / 2 / 6 measured the same within 1 % (0.279-0.281 ms on
+    // the 14 x 14 layer, profiles/r02_conv_pp_dma_split.txt); the $SMIRK_PP_NL switch and those instantiations left the library in round 5.
     const int ntm = (a.M + PP_BM - 1) / PP_BM, ntn = a.N / PP_BN;
     if (g_smirk_prof_on) {
         const double px = (double)a.d.B * a.d.H * a.d.W;
-        char nm[64];
-        snprintf(nm, sizeof(nm), "conv_pp_kernel<%d>[256x128,8w,3stage]", nl == 6 ? 6 : nl == 0 ? 0 : nl == 2 ? 2 : 3);
-        smirk_prof_next(nm, 2.0 * a.M * a.N * a.K,
+        smirk_prof_next("conv_pp_kernel<3>[256x128,8w,3stage]", 2.0 * a.M * a.N * a.K,
                         4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
     }
-    if (nl == 6) SMIRK_LAUNCH(conv_pp_kernel<6>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
-    else if (nl == 0) SMIRK_LAUNCH(conv_pp_kernel<0>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
-    else if (nl == 2) SMIRK_LAUNCH(conv_pp_kernel<2>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
-    else SMIRK_LAUNCH(conv_pp_kernel<3>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
+    SMIRK_LAUNCH(conv_pp_kernel<3>, dim3(ntm * ntn), dim3(512), PP_LDS_BYTES, st, a);
     return smirk_launch_status();
 }

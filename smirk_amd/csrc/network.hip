@@ -135,32 +135,45 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     // side streams, forked / joined with events): while one chain's layer drains its partial last round the other chain's workgroups take the free CUs.
     // Bit-identical results (batch invariance, tests/test_scale_gpu.py run with it forced).  Measured with the RCCL gather enqueued, same box (profiles/r04l_, r04m_,
     // r04n_): +3.2 % at 128 frames per pass, +4.5 % at 256, +1.2 % at 1024 for the H/8 + H/16 part -> taken when > 5 % of a 14 x 14 layer's last round would idle.
-    // $SMIRK_GEN_SPLIT_CHAINS=0 / 2 / 3 selects the number of chains, $SMIRK_GEN_CHAIN_FROM=2 / 3 the first level of the section: 3 (H/8) by default — starting at H/4
-    // measured 8,801 vs 8,857 faces/s at 128 frames, 9,406 vs 9,473 at 256, 9,872 vs 9,782 at 1024 (profiles/r04n_chain_from.txt): the 56 x 56 layers fill their rounds.
+    // $SMIRK_GEN_SPLIT_CHAINS=0 / 2 / 3 selects the number of chains (the A/B switch of tests/test_generator_gpu.py).  The section starts at H/8: starting it at H/4
+    // measured 8,801 vs 8,857 faces/s at 128 frames, 9,406 vs 9,473 at 256, 9,872 vs 9,782 at 1024 (profiles/r04n_chain_from.txt; the 56 x 56 layers fill their rounds) and
+    // the switch for it left the library.  Batches below 16 frames are never split by the heuristic (a fork / join costs more than the idle part of their only round).
     const int h16 = H >> 4, w16 = W >> 4, c16 = f << 4;
-    int nchain = 1, L0 = 3;
-    if (const char* e = getenv("SMIRK_GEN_CHAIN_FROM")) L0 = e[0] == '3' ? 3 : 2;
+    const int L0 = 3;
+    int nchain = 1;
     if (B >= 2 && !taps && !g_smirk_prof_on) {                      // (taps copy whole tensors; the launch profiler times launches on ONE stream)
         static int n_cu = 0;
-        if (n_cu == 0) { int dev = 0, cus = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; n_cu = cus; }
+        if (n_cu == 0) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+            n_cu = cus;
+        }
         const double rounds = ((double)B * h16 * w16 / 256.0) * (c16 / 128.0) / n_cu;      // 256 x 128 tiles of a 14 x 14 layer per CU
         const double full = (double)(long long)(rounds + 0.999999);
-        if (full > 0 && (full - rounds) / full > 0.05) nchain = 2;
+        if (B >= 16 && full > 0 && (full - rounds) / full > 0.05) nchain = 2;
         if (const char* e = getenv("SMIRK_GEN_SPLIT_CHAINS")) nchain = e[0] == '0' ? 1 : e[0] == '3' ? 3 : 2;
         if (nchain > B) nchain = B;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (nchain > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) nchain = 1;
+    if (nchain > 1 && (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) { (void)hipGetLastError(); nchain = 1; }
+    // Side streams and the fork / join events are owned per HOST THREAD and device (thread_local): two threads driving the same device neither race on the lazy
+    // creation nor record / wait on each other's events; created once, reused by every forward of that thread (re-recording an event only affects later waits).
     hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     if (nchain > 1) {
-        static hipStream_t side_dev[64][2] = {};                     // side streams per device, created on first use
+        thread_local hipStream_t side_dev[64][2] = {};
+        thread_local hipEvent_t ev_dev[64][3] = {};
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) nchain = 1;
-        else
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); nchain = 1; }
+        else {
+            for (int k = 0; k < 3 && nchain > 1; ++k)
+                if (!ev_dev[dev][k] && hipEventCreateWithFlags(&ev_dev[dev][k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_dev[dev][k] = nullptr; nchain = 1; }
             for (int k = 0; k + 1 < nchain; ++k) {
-                if (!side_dev[dev][k] && hipStreamCreateWithFlags(&side_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { side_dev[dev][k] = nullptr; nchain = 1; break; }
+                if (!side_dev[dev][k] && hipStreamCreateWithFlags(&side_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side_dev[dev][k] = nullptr; nchain = 1; break; }
                 side[k] = side_dev[dev][k];
             }
+            fork = ev_dev[dev][0]; join[0] = ev_dev[dev][1]; join[1] = ev_dev[dev][2];
+        }
     }
     // ---- encoder levels above the section, whole batch (smirk_generator.py:52-57) --------------------------------------------------------------------------
     const void* cur = p.x;
@@ -261,25 +274,26 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     };
     const void* dcur = nullptr;
     if (nchain > 1) {
-        hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-        int rc = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess ? SMIRK_OK : SMIRK_ERR_LAUNCH;
-        for (int k = 0; rc == SMIRK_OK && k + 1 < nchain; ++k)
-            if (hipEventCreateWithFlags(&join[k], hipEventDisableTiming) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
-        if (rc == SMIRK_OK && hipEventRecord(fork, (hipStream_t)stream) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
+        int rc = hipEventRecord(fork, (hipStream_t)stream) == hipSuccess ? SMIRK_OK : SMIRK_ERR_LAUNCH;
         const void* last = nullptr;
+        bool forked[2] = {false, false};
         for (int k = nchain - 1; rc == SMIRK_OK && k >= 0; --k) {   // chain k owns frames [B k / n, B (k+1) / n); chain 0 runs on the caller's stream, enqueued last
             const int b0 = (int)((long long)B * k / nchain), b1 = (int)((long long)B * (k + 1) / nchain);
             hipStream_t st_k = k == 0 ? (hipStream_t)stream : side[k - 1];
             if (k > 0 && hipStreamWaitEvent(st_k, fork, 0) != hipSuccess) { rc = SMIRK_ERR_LAUNCH; break; }
+            if (k > 0) forked[k - 1] = true;
             rc = deep(k, b0, b1 - b0, (void*)st_k, cur, last);
             if (rc == SMIRK_OK && k > 0 && hipEventRecord(join[k - 1], st_k) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
         }
         for (int k = 0; rc == SMIRK_OK && k + 1 < nchain; ++k)
             if (hipStreamWaitEvent((hipStream_t)stream, join[k], 0) != hipSuccess) rc = SMIRK_ERR_LAUNCH;
-        if (fork) (void)hipEventDestroy(fork);                       // destruction is deferred until the recorded work has completed
-        for (int k = 0; k < 2; ++k)
-            if (join[k]) (void)hipEventDestroy(join[k]);
-        if (rc != SMIRK_OK) return rc;
+        if (rc != SMIRK_OK) {
+            // a chain failed part-way: whatever was enqueued on the side streams still reads / writes the caller's workspace.  The caller's stream must not run
+            // ahead of it (the workspace may be reused or freed in stream order), so the side streams are drained before the error is returned.
+            for (int k = 0; k < 2; ++k)
+                if (forked[k]) (void)hipStreamSynchronize(side[k]);
+            return rc;
+        }
         dcur = last;
     } else {
         TRY(deep(0, 0, B, stream, cur, dcur));
@@ -365,7 +379,8 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
     if (ws_bytes < p.total) return SMIRK_ERR_WORKSPACE;
     const bool split = w->precision == SMIRK_PRECISION_F16X3;
     const bool no_image = getenv("SMIRK_DISABLE_MBCONV_IMAGE") != nullptr;                                                       // A/B switch (tests)
-    const bool no_fuse = getenv("SMIRK_DISABLE_MBCONV_FUSED") != nullptr, fuse_ds = getenv("SMIRK_MBCONV_FUSE_DS") != nullptr;   // A/B switches (tests)
+    const bool no_fuse = getenv("SMIRK_DISABLE_MBCONV_FUSED") != nullptr;                                                         // A/B switch (tests)
+    const bool fuse_ds = false;       // DepthwiseSeparable blocks stay unfused (no expanded tensor to save: 202 vs 200 us at stride 1, 97 vs 66 at stride 2)
     int h = (H + 1) / 2, wd = (W + 1) / 2;
     void* x = p.rot.slot[0];
     // stem + first DepthwiseSeparable block in one launch (encoder_head.hip): the 16-channel 112 x 112 tensors between them never reach HBM

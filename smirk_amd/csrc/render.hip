@@ -322,9 +322,14 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
                        frec, fbox);
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     const size_t smem = FACE_CHUNK * FACE_REC * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
+#ifdef SMIRK_DEBUG_HOOKS                                            /* -DSMIRK_DEBUG_HOOKS variant builds only (tools/build_variant.sh, tools/raster_time.py) */
     static const char* abl = getenv("SMIRK_RASTER_ABLATE");      // 1: no per-pixel face loop, 2: no binning scan (timing experiments; wrong images)
+    const int ablate = abl ? atoi(abl) : 0;
+#else
+    const int ablate = 0;
+#endif
     SMIRK_LAUNCH(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
-                       (long long*)pix_to_face, bary, zbuf, abl ? atoi(abl) : 0);
+                       (long long*)pix_to_face, bary, zbuf, ablate);
     return smirk_launch_status();
 }
 

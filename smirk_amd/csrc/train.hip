@@ -1143,8 +1143,7 @@ extern "C" int smirk_conv1x1_sigmoid_backward_split16(const float* dy, const flo
 }
 
 static bool wgrad_halo_ok(int W, int Cout, int Cin, int KH, int reflect) {
-    static const char* off = getenv("SMIRK_WGRAD_HALO");                     // "0" forces the generic kernel (A/B)
-    return KH == 3 && !reflect && W % 16 == 0 && (Cout == 32 || Cout == 64) && (Cin == 32 || Cin == 64) && !(off && off[0] == '0');
+    return KH == 3 && !reflect && W % 16 == 0 && (Cout == 32 || Cout == 64) && (Cin == 32 || Cin == 64);
 }
 // $SMIRK_WGRAD_F16: "0" = exact-fp32 MFMA kernel (wgrad_kernel), "1" / "2" = split-fp16 x3 kernel with 1 / 2 chunks per barrier (default 2);
 // "+16" (17 / 18) selects the alternative lane geometry of the LDS transpose read (diagnostic)
@@ -1167,8 +1166,7 @@ static int wgrad_nsplit(long long npix, int Cout, int N) {
     }
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const long long tiles = (long long)((Cout + TM - 1) / TM) * ((N + 127) / 128);
-    static const int wg_env = [] { const char* e = getenv("SMIRK_WGRAD_SPLIT_WG"); return e ? atoi(e) : 0; }();   // A/B: workgroups the K splits should add up to
-    long long want = (wg_env > 0 ? wg_env : (TM == 128 ? 1024 : 1536)) / tiles;   // 4 (TM = 128: 34 KB LDS each) / 6 workgroups per CU in ONE round (rounding up put 1152 on
+    long long want = (TM == 128 ? 1024 : 1536) / tiles;   // 4 (TM = 128: 34 KB LDS each) / 6 workgroups per CU in ONE round (rounding up put 1152 on
                                                                        // 1024 slots for the 512-channel layers: a second, 12 % full round)
     if (want > WG_MAX_SPLIT) want = WG_MAX_SPLIT;
     if (want > chunks) want = chunks;

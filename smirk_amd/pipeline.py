@@ -73,10 +73,13 @@ class OverlappedPipeline:
         self.pipe = pipe
         self.n_gen = int(generator_streams)
         import smirk_amd
-        if smirk_amd.HW_QUEUES_TOO_LATE or int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 + 2 * self.n_gen:
+        # streams of one step: front, 3 backbones, n_gen generator streams with a chain side stream each, the collective's stream, the caller's
+        n_streams = 6 + 2 * self.n_gen
+        if smirk_amd.HW_QUEUES_TOO_LATE or int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < n_streams:
             warnings.warn("OverlappedPipeline runs on %d HIP streams but the HIP runtime multiplexes them onto %s hardware queues (packets of a shared queue "
-                          "retire in order): export GPU_MAX_HW_QUEUES=16 before the process first touches the GPU (smirk_amd sets it when imported first)"
-                          % (5 + 2 * self.n_gen, "4 (its default, read before smirk_amd was imported)" if smirk_amd.HW_QUEUES_TOO_LATE
+                          "retire in order; results are unaffected, overlap is lost): export GPU_MAX_HW_QUEUES=16 before the process starts (smirk_amd sets it "
+                          "when it is imported before the first HIP call)"
+                          % (n_streams, "4 (its default, read before smirk_amd was imported)" if smirk_amd.HW_QUEUES_TOO_LATE
                              else os.environ.get("GPU_MAX_HW_QUEUES")), stacklevel=2)
         self.front_stream, self.gen_streams = None, None
         self._waiting = []                         # front done, generator not enqueued yet: (outputs, masked, front-done event)

@@ -238,7 +238,7 @@ class MobileNetV3Features(nn.Module):
 
     @staticmethod
     def _fusable(lib, cin, pk, blk):
-        if blk.kind == "ds" and not os.environ.get("SMIRK_MBCONV_FUSE_DS"):
+        if blk.kind == "ds":
             return False        # measured: no expanded tensor to keep on chip, the two streaming kernels are as fast (s1) or faster (s2)
         return bool(lib.smirk_mbconv_supported(cin, pk["dw"][0].shape[1], pk["pw" if blk.kind == "ds" else "pwl"][0].shape[0], blk.stride))
 
@@ -260,7 +260,7 @@ class MobileNetV3Features(nn.Module):
     def forward(self, img, _taps=None):
         """img [B,3,H,W] NCHW in [0,1] -> last feature map NHWC [B,H/32,W/32,C] (fp32, or split16 storage when PRECISION == "f16x3":
         see `features_f32`).  `_taps` (list) collects the stem output and every block's output (debugging / parity tools)."""
-        if _taps is None and not os.environ.get("SMIRK_PY_LAYER_SCHEDULE"):
+        if _taps is None:
             return self.run(img, want_features=True)[1]
         # per-layer schedule driven from Python: the debugging twin of smirk_backbone_forward (same kernels, same order), kept for `_taps`
         if self.training:

@@ -72,6 +72,11 @@ def _pack3x3(w, cin_pad=None):
 
 
 class SmirkGenerator(nn.Module):
+    """Drop-in for src/smirk_generator.py:SmirkGenerator (same constructor, state_dict keys and forward).  Limits of the gfx950 kernels, all reported by
+    exceptions: init_features % 8 == 0 and out_channels <= 4 (constructor); input H, W multiples of 16 (the reference's own skip `torch.cat` fails otherwise);
+    in_channels > 8 is served for gradient-free inference only (exact-fp32 kernels) — train mode and eval-mode input gradients need in_channels <= 8
+    (SMIRK uses 6)."""
+
     def __init__(self, in_channels=3, out_channels=1, init_features=16, res_blocks=3):
         super().__init__()
         f = init_features
@@ -185,11 +190,21 @@ class SmirkGenerator(nn.Module):
             # real backward pass — one autograd.Function over the whole network (smirk_amd/generator_train.py, csrc/train.hip)
             if self.precision != "f16x3":
                 raise L.SmirkHipError("train mode runs in the split-fp16 ('f16x3') arithmetic mode")
+            if self.in_channels > 8:
+                raise L.SmirkHipError("smirk_amd.SmirkGenerator: train mode / backward need in_channels <= 8 (one split16 channel group at the network input); "
+                                      "in_channels > 8 is served for gradient-free inference only (exact-fp32 kernels)")
             from .generator_train import GeneratorTrainFunction
             x = a if b is None else torch.cat([a, b], 1)
             return GeneratorTrainFunction.apply(self, x, *self.parameters())
         srcs = [a] + ([] if b is None else [b])
-        if taps is None and self.precision == "f16x3" and torch.is_grad_enabled() and any(t.requires_grad for t in srcs):
+        wants_input_grad = taps is None and torch.is_grad_enabled() and any(t.requires_grad for t in srcs)
+        if wants_input_grad and (self.precision != "f16x3" or self.in_channels > 8):
+            # decided on the EFFECTIVE arithmetic (in_channels > 8 runs the exact-fp32 kernels even when precision == "f16x3"): say so now instead of failing
+            # inside the autograd function or handing back a tensor whose backward raises later
+            raise L.SmirkHipError("smirk_amd.SmirkGenerator: a gradient with respect to the input is available in the split-fp16 ('f16x3') mode with "
+                                  "in_channels <= 8 only (this module runs the exact-fp32 inference kernels: precision=%r, in_channels=%d)"
+                                  % (self.precision, self.in_channels))
+        if wants_input_grad:
             # eval mode with an INPUT that requires grad — smirk_trainer.py:108-113 freezes the generator, calls .eval() and back-propagates the emotion
             # loss through it into rendered_img: the same autograd.Function as train mode with BatchNorm taken from the running statistics.  (Forward-only
             # callers whose parameters merely have requires_grad=True, like demo.py without no_grad, stay on the whole-network C entry below.)

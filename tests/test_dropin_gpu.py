@@ -139,3 +139,59 @@ def test_renderer_full_head_returns_the_shifted_z(in_sandbox):
     assert torch.equal(a["transformed_vertices"][..., :2], b["transformed_vertices"][..., :2])
     assert torch.allclose(b["transformed_vertices"][..., 2], a["transformed_vertices"][..., 2] + 10)
     assert (b["rendered_img"] != 0).float().mean() >= (a["rendered_img"] != 0).float().mean()      # the whole head covers at least the face
+
+
+_LATE_IMPORT = r"""
+import os, sys, warnings, tempfile
+sys.path.insert(0, {repo!r})
+os.environ.pop("GPU_MAX_HW_QUEUES", None)
+late = {late}
+import torch
+if late:
+    torch.cuda.init(); torch.zeros(1, device="cuda")           # the HIP runtime has read its default of 4 hardware queues
+import smirk_amd
+from smirk_amd import FLAME, Renderer, SmirkEncoder, SmirkGenerator
+from smirk_amd.pipeline import OverlappedPipeline, SmirkPipeline
+from oracle import assets as A, generator_ref as G, mobilenet_ref as M
+sb = tempfile.mkdtemp(); A.write_sandbox(sb); os.chdir(sb)
+dev = "cuda"
+enc = SmirkEncoder(); enc.load_state_dict(M.synth_encoder_state_dict()); enc = enc.to(dev).eval()
+gen = SmirkGenerator(6, 3, 32, 5); gen.load_state_dict(G.synth_state_dict()); gen = gen.to(dev).eval()
+pipe = SmirkPipeline(enc, FLAME().to(dev), Renderer().to(dev), gen)
+img = A.synth_images(8, seed=11).to(dev)
+masked = A.synth_generator_input(8, seed=11)[:, 3:].contiguous().to(dev)
+serial = pipe(img, masked)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    run = OverlappedPipeline(pipe, generator_streams=2)
+warned = any("hardware queues" in str(x.message) for x in w)
+outs = []
+for _ in range(3):
+    d = run.submit(img, masked)
+    if d is not None: outs.append(d)
+while (d := run.flush()) is not None: outs.append(d)
+torch.cuda.synchronize()
+same = all(torch.equal(o[k], serial[k]) for o in outs for k in ("vertices", "rendered_img", "reconstructed_img", "expression_params"))
+import hashlib
+h = hashlib.sha256(b"".join(serial[k].cpu().numpy().tobytes() for k in ("vertices", "rendered_img", "reconstructed_img"))).hexdigest()[:16]
+print("RESULT", smirk_amd.HW_QUEUES_STATE, warned, len(outs), same, h)
+"""
+
+
+def test_late_import_warns_and_results_do_not_depend_on_the_hardware_queue_count():
+    """`import torch; torch.cuda.init(); import smirk_amd`: the runtime keeps its 4 hardware queues (streams share queues, overlap is lost), the package says so
+    through HW_QUEUES_STATE and OverlappedPipeline's warning, and every output is bit-identical to the in-time import (16 queues) and to the serial pipeline."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for late in (True, False):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        r = subprocess.run([sys.executable, "-c", _LATE_IMPORT.format(repo=repo, late=late)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[late] = next(ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")).split()[1:]
+    state, warned, n, same, h_late = res[True]
+    assert state == "too-late" and warned == "True" and n == "3" and same == "True"
+    state, warned, n, same, h_time = res[False]
+    assert state == "default-after-torch" and warned == "False" and n == "3" and same == "True"
+    assert h_late == h_time

@@ -127,3 +127,38 @@ def test_generator_shapes_the_split_layout_cannot_carry_run_in_exact_fp32(cin, f
         m(torch.rand(1, cin, 40, 40).cuda())
     with pytest.raises(Exception, match="init_features % 8"):
         SmirkGenerator(in_channels=6, out_channels=3, init_features=12, res_blocks=1)
+
+
+def test_generator_in_channels_above_8_refuses_gradients_up_front():
+    """in_channels > 8 is an inference-only shape (exact-fp32 kernels): train mode and an eval-mode input gradient say so when they are ASKED for, not when a
+    backward pass finally needs them."""
+    from smirk_amd import SmirkGenerator, SmirkHipError
+    m = SmirkGenerator(in_channels=10, out_channels=3, init_features=16, res_blocks=1).cuda().eval()
+    x = torch.rand(1, 10, 32, 32, device="cuda", requires_grad=True)
+    with pytest.raises(SmirkHipError, match="gradient with respect to the input"):
+        m(x)
+    m.train()
+    with pytest.raises(SmirkHipError, match="in_channels <= 8"):
+        m(x.detach())
+
+
+@pytest.mark.parametrize("chains", ["0", "2", "3"])
+@pytest.mark.parametrize("B", [3, 20])
+def test_generator_sub_batch_chains_are_bitwise_the_single_chain(chains, B, monkeypatch):
+    """smirk_generator_forward runs the H/8 + H/16 section as 1 / 2 / 3 sub-batch chains on side streams (csrc/network.hip); every frame's result must be the
+    single-chain result bit for bit, for batches that do not divide evenly too.  $SMIRK_GEN_SPLIT_CHAINS forces the chain count (read per call)."""
+    from smirk_amd import SmirkGenerator
+    sd = G.synth_state_dict()
+    m = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = A.synth_generator_input(B, seed=31).cuda()
+    monkeypatch.setenv("SMIRK_GEN_SPLIT_CHAINS", "0")
+    with torch.no_grad():
+        ref = m(x).clone()
+    monkeypatch.setenv("SMIRK_GEN_SPLIT_CHAINS", chains)
+    with torch.no_grad():
+        for _ in range(3):                                                       # repeated: the side streams and events are reused across calls
+            y = m(x)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref)
