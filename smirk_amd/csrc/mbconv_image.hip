@@ -74,7 +74,9 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
     auto load_we = [&](int c) {
         // channels beyond mid (ragged last chunk): the fragments of a clamped row are loaded unconditionally (no branches in the loop) and the chunk's
         // BN constants are zeroed instead, so E = relu(finite * 0 + 0) = 0 there
-        const int ch = 32 * c + fr;
+        int frw = fr;
+        asm volatile("" : "+v"(frw));
+        const int ch = 32 * c + frw;
         const bool v = ch < a.mid;
         const int chc = min(ch, a.mid - 1);
         const char* wrow = a.wexp + (size_t)chc * xrow;
@@ -92,9 +94,11 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
     f32x4 wpv[2];
     float wcv = 0.f;
     auto fetch_stage = [&](int c) {
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));                     // addresses re-derived per chunk: hoisted out of the chunk loop they are six more live registers (-> scratch at NT = 4)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int idx = tid + 512 * u, row = idx >> 3, piece = idx & 7, kg = 4 * c + (piece >> 1);
+            const int idx = t0 + 512 * u, row = idx >> 3, piece = idx & 7, kg = 4 * c + (piece >> 1);
             const bool ok = row < a.Cout && kg * 8 < a.mid;
             const int rc = min(row, a.Cout - 1), kc = min(kg, a.mid / 8 - 1);
             const f32x4 t = *(const f32x4*)(a.wproj + ((size_t)rc * a.mid + kc * 8) * 4 + (piece & 1) * 16);
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
             wpv[u] = ok ? t : z;
         }
         {   // 11 x 32 depthwise / BN constants: wdw is [9][mid], s2 and b2 follow the same indexing through a pointer select
-            const int k = min(tid >> 5, 10), ch = 32 * c + (tid & 31), chc = min(ch, a.mid - 1);
+            const int k = min(t0 >> 5, 10), ch = 32 * c + (t0 & 31), chc = min(ch, a.mid - 1);
             const float* src = k < 9 ? a.wdw + (size_t)k * a.mid : (k == 9 ? a.s2 : a.b2);
             const float t = src[chc];
             wcv = ch < a.mid ? t : 0.f;
@@ -110,12 +114,14 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
     };
     auto store_stage = [&](int c) {
         char* dst = Wp + (c & 1) * wpbuf;
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int idx = tid + 512 * u, row = idx >> 3, piece = idx & 7;
+            const int idx = t0 + 512 * u, row = idx >> 3, piece = idx & 7;
             if (row < a.Cout) *(f32x4*)(dst + row * 144 + piece * 16) = wpv[u];
         }
-        if (tid < 352) Wc[(c & 1) * 352 + tid] = wcv;
+        if (t0 < 352) Wc[(c & 1) * 352 + t0] = wcv;
     };
 
     // ---- phase 0: x -> LDS, zero grid, row -> grid map ----------------------------------------------------------------------------------------------
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
             e0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, we[s][0], e0, 0, 0, 0);
             e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, we[s][1], e1, 0, 0, 0);
             e1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, we[s][0], e1, 0, 0, 0);
-            if (s & 1) __builtin_amdgcn_sched_barrier(0);      // at most two k-steps of A fragments in flight: the register file is full (128 accumulators)
+            if ((s & 1) || NT == 4) __builtin_amdgcn_sched_barrier(0);      // at most two k-steps (NT = 4: one) of A fragments in flight: the register file is full (128 accumulators)
         }
         int rbase = wave * 32 + 4 * hb;                 // row of accumulator register r: rbase + (r & 3) + 8 (r >> 2)
         asm volatile("" : "+v"(rbase));                 // re-read the 16 grid positions from LDS every chunk instead of keeping them in registers
@@ -233,9 +239,11 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
         if (more) load_we(c + 1);                       // lands under the project MFMAs
         if (c >= 0 && active) {
             const char* wp = Wp + (c & 1) * wpbuf;
+            int frq = fr;
+            asm volatile("" : "+v"(frq));               // the NT row addresses are re-derived per chunk (hoisted they are NT more live registers)
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                const int co = min(q * 32 + fr, a.Cout - 1);      // columns beyond Cout duplicate the last row and are never stored
+                const int co = min(q * 32 + frq, a.Cout - 1);     // columns beyond Cout duplicate the last row and are never stored
                 const char* brow = wp + co * 144;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {

@@ -21,7 +21,7 @@
 #define TILE_W 32
 #define TILE_H 8
 #define FACE_CHUNK 64
-#define FACE_REC 20               // floats per staged face record in raster_tile
+#define FACE_REC 24               // floats per staged face record in raster_tile (21 used; 96-byte rows: six aligned 16-byte reads)
 #define K_EPS 1e-8f
 
 struct MeshDev {
@@ -115,15 +115,23 @@ __device__ inline short4 face_pixel_box(const float* p, int H, int W) {
     return box;
 }
 
-// face record: 9 floats (x0,y0,z0,x1,y1,z1,x2,y2,z2) in pytorch3d NDC;  bbox: conservative pixel-index box (xi0,xi1,yi0,yi1),
-// empty (xi0 > xi1) for faces the reference skips wholesale (|area| <= eps, zmin < eps).
-__global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H, int W, const float* __restrict__ tv,
-                                                         float* __restrict__ frec, short4* __restrict__ fbox) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * m.Ff) return;
-    const int b = (int)(i / m.Ff), f = (int)(i % m.Ff);
-    const float* tb = tv + (size_t)b * m.V * 3;
-    float p[9];
+// ---- per-frame face setup, sorted front to back -------------------------------------------------------------------------------------------------------------
+// Record of a face in the workspace (FREC_G = 12 floats): x0,y0,z0,x1,y1,z1,x2,y2,z2 in pytorch3d NDC (sub-mesh select, xy negation, z + 10: renderer.py:139-144,
+// 172-173), zlow, the face id (int bits), pad; bbox: conservative pixel-index box (xi0,xi1,yi0,yi1), empty (xi0 > xi1) for faces the reference skips wholesale
+// (|area| <= eps, zmin < eps).  Records are stored in ASCENDING zlow order (valid faces first; nvalid[b] of them).
+//
+// zlow is a proven lower bound of the depth pz the per-pixel code of raster_tile can compute for ANY pixel this face covers:
+//     pz = fl(fl(fl(w0 z0) + fl(w1 z1)) + fl(w2 z2)),  w_k = fl(e_k / A) > 0,  z_k >= zmin   =>   pz >= zmin (w0 + w1 + w2) (1 - 4u),      u = 2^-24
+//     e_k (computed, -ffp-contract=off) differs from the exact edge function by <= 8u ext^2 for a pixel inside the face's box (ext = box width + height in NDC),
+//     the exact edge functions sum to the exact doubled area, and A = fl(area_computed + 1e-8)   =>   w0 + w1 + w2 >= 1 - 2u - (1e-8 + 32u ext^2) / |A|
+// zlow = zmin (1 - rho)(1 - 2e-6) with rho = (1e-8 + 128u ext^2) / |A| (4x the derived error term), and 0 when rho is not small or z is tiny.  A face whose zlow
+// is STRICTLY above the current depth of every pixel of a block cannot win the (pz, face) lexicographic minimum anywhere in it: skipping it leaves pix_to_face,
+// the barycentrics and the z-buffer bit-identical (the reference's K = 1 result does not depend on the order faces are visited in).  On SURVEY 8(d)'s synthetic
+// basis the projected mesh is a crumpled sheet (3408 triangles of ~240 px^2 over a 17 k px silhouette: ~24 layers), which is what made the face loop 5 % of the step.
+#define FREC_G 12
+#define SORT_N 4096               // faces per frame the in-LDS bitonic sort handles (SMIRK's sub-mesh: 3408); larger meshes keep the mesh order and zlow = 0
+
+__device__ __forceinline__ void face_corners(const MeshDev& m, const float* tb, int f, float* p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int g = m.keep[m.faces[f * 3 + k]];
@@ -131,40 +139,131 @@ __global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H
         p[k * 3 + 1] = -tb[g * 3 + 1];
         p[k * 3 + 2] = tb[g * 3 + 2] + 10.0f;
     }
+}
+__device__ __forceinline__ float face_zlow(const float* p) {
+    const float xmin = fminf(p[0], fminf(p[3], p[6])), xmax = fmaxf(p[0], fmaxf(p[3], p[6]));
+    const float ymin = fminf(p[1], fminf(p[4], p[7])), ymax = fmaxf(p[1], fmaxf(p[4], p[7]));
+    const float zmin = fminf(p[2], fminf(p[5], p[8]));
+    const float A = edge_fn(p[6], p[7], p[0], p[1], p[3], p[4]) + K_EPS;           // the value raster_tile divides by
+    const float ext = (xmax - xmin) + (ymax - ymin);
+    const float rho = (1e-8f + 7.63e-6f * ext * ext) / fabsf(A);                  // 128 u = 7.63e-6
+    if (!(rho < 0.25f) || !(zmin > 1e-3f)) return 0.f;                             // (NaN / inf / degenerate faces land here too)
+    return zmin * (1.0f - rho) * (1.0f - 2e-6f);
+}
+__device__ __forceinline__ void store_face(float* frec, short4* fbox, size_t slot, const float* p, float zlow, int f, short4 box) {
+    float* r = frec + slot * FREC_G;
+    *(float4*)r = make_float4(p[0], p[1], p[2], p[3]);
+    *(float4*)(r + 4) = make_float4(p[4], p[5], p[6], p[7]);
+    *(float4*)(r + 8) = make_float4(p[8], zlow, __int_as_float(f), 0.f);
+    fbox[slot] = box;
+}
+
+// meshes beyond SORT_N faces: mesh order, no depth bound (the tile kernel then visits every binned face, as rounds 1-4 did)
+__global__ __launch_bounds__(256) void raster_face_setup(MeshDev m, int B, int H, int W, const float* __restrict__ tv,
+                                                         float* __restrict__ frec, short4* __restrict__ fbox, int* __restrict__ nvalid) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * m.Ff) return;
+    const int b = (int)(i / m.Ff), f = (int)(i % m.Ff);
+    float p[9];
+    face_corners(m, tv + (size_t)b * m.V * 3, f, p);
+    store_face(frec, fbox, i, p, 0.f, f, face_pixel_box(p, H, W));
+    if (f == 0) nvalid[b] = m.Ff;
+}
+
+// one workgroup per frame: keys (zlow bits << 32 | face) of the valid faces, bitonic sort in LDS, records written in sorted order
+__global__ __launch_bounds__(512) void raster_face_setup_sorted(MeshDev m, int B, int H, int W, const float* __restrict__ tv,
+                                                                float* __restrict__ frec, short4* __restrict__ fbox, int* __restrict__ nvalid) {
+    __shared__ unsigned long long key[SORT_N];
+    __shared__ int cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* tb = tv + (size_t)b * m.V * 3;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int f = tid; f < SORT_N; f += 512) {
+        unsigned long long k = ~0ull;                                               // invalid / padding: sorts last
+        if (f < m.Ff) {
+            float p[9];
+            face_corners(m, tb, f, p);
+            const short4 box = face_pixel_box(p, H, W);
+            if (box.x <= box.y) { k = ((unsigned long long)__float_as_uint(face_zlow(p)) << 32) | (unsigned)f; ++mine; }   // zlow >= 0: its bits order like the value
+        }
+        key[f] = k;
+    }
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    for (int k2 = 2; k2 <= SORT_N; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < SORT_N / 2; t += 512) {
+                const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1)), i1 = i0 | j;       // the pair (i0, i0 + j) of this compare-exchange step
+                const bool up = (i0 & k2) == 0;
+                const unsigned long long a = key[i0], c = key[i1];
+                if ((a > c) == up) { key[i0] = c; key[i1] = a; }
+            }
+            __syncthreads();
+        }
+    const int nv = cnt;
+    if (tid == 0) nvalid[b] = nv;
+    for (int s = tid; s < m.Ff; s += 512) {
+        const size_t slot = (size_t)b * m.Ff + s;
+        if (s < nv) {
+            const int f = (int)(unsigned)(key[s] & 0xFFFFFFFFull);
+            float p[9];
+            face_corners(m, tb, f, p);
+            store_face(frec, fbox, slot, p, __uint_as_float((unsigned)(key[s] >> 32)), f, face_pixel_box(p, H, W));
+        } else {
+            fbox[slot] = make_short4(1, 0, 1, 0);                                   // never binned
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) frec[i * 9 + k] = p[k];
-    const short4 box = face_pixel_box(p, H, W);
-    fbox[i] = box;
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int W, const float* __restrict__ frec,
-                                                   const short4* __restrict__ fbox, const float* __restrict__ normals,
+                                                   const short4* __restrict__ fbox, const int* __restrict__ nvalid, const float* __restrict__ normals,
                                                    float* __restrict__ img, long long* __restrict__ p2f_out,
-                                                   float* __restrict__ bary_out, float* __restrict__ zbuf_out, int ablate) {
+                                                   float* __restrict__ bary_out, float* __restrict__ zbuf_out, int qmax, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    // layout: [FACE_CHUNK*FACE_REC floats][FACE_CHUNK ints][1 int counter (+3 pad)][Ff uint16 list]
+    // layout: [FACE_CHUNK*FACE_REC floats][FACE_CHUNK ints][8 ints: per-wave list counts, 4 floats: per-wave block depth][4 x qmax uint16 lists]
     float* sface = (float*)dyn_smem;
     int* sfid = (int*)(sface + FACE_CHUNK * FACE_REC);
-    int* scount = sfid + FACE_CHUNK;
-    unsigned short* slist = (unsigned short*)(scount + 4);
+    int* scnt = sfid + FACE_CHUNK;
+    float* szmx = (float*)(scnt + 4);
+    unsigned short* slist = (unsigned short*)(scnt + 8);
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (W + TILE_W - 1) / TILE_W;
     const int b = blockIdx.y;
     const int tx0 = (blockIdx.x % tiles_x) * TILE_W, ty0 = (blockIdx.x / tiles_x) * TILE_H;
     const int tx1 = min(tx0 + TILE_W, W) - 1, ty1 = min(ty0 + TILE_H, H) - 1;
-    if (tid == 0) *scount = 0;
-    __syncthreads();
+    // ---- binning, order-preserving: wave w scans the sorted faces [w q, (w + 1) q) and compacts the ones whose box touches the tile into ITS list with a ballot
+    // prefix (no atomics: the concatenation of the four lists is again in ascending zlow order)
     const short4* boxes = fbox + (size_t)b * m.Ff;
-    for (int f = tid; f < ((ablate & 2) ? 0 : m.Ff); f += 256) {          // ablate: timing experiments only ($SMIRK_RASTER_ABLATE)
-        const short4 bx = boxes[f];
-        if (bx.x <= tx1 && bx.y >= tx0 && bx.z <= ty1 && bx.w >= ty0 && bx.x <= bx.y) {
-            const int slot = atomicAdd(scount, 1);
-            slist[slot] = (unsigned short)f;
+    const int nv = (ablate & 2) ? 0 : nvalid[b];
+    {
+        const int q = ((nv + 3) / 4 + 63) & ~63, lo = wave * q, hi = min(lo + q, nv);
+        unsigned short* mylist = slist + wave * qmax;
+        int c = 0;
+        for (int base = lo; base < hi; base += 64) {
+            const int s = base + lane;
+            bool hit = false;
+            if (s < hi) {
+                const short4 bx = boxes[s];
+                hit = bx.x <= tx1 && bx.y >= tx0 && bx.z <= ty1 && bx.w >= ty0 && bx.x <= bx.y;
+            }
+            const unsigned long long mk = __ballot(hit);
+            if (hit) mylist[c + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)s;
+            c += __popcll(mk);
         }
+        if (lane == 0) scnt[wave] = c;
     }
     __syncthreads();
-    const int n = (ablate & 1) ? 0 : *scount;
+    const int n0 = scnt[0], n1 = n0 + scnt[1], n2 = n1 + scnt[2];
+    const int n = (ablate & 1) ? 0 : n2 + scnt[3];
 
     // a wave owns an 8 x 8 pixel block of the 32 x 8 tile (not a 32 x 2 strip): with face boxes of ~20 px the block is touched by 1.5x fewer faces
     const int xi = tx0 + (tid >> 6) * 8 + (tid & 7), yi = ty0 + ((tid & 63) >> 3);
@@ -172,21 +271,28 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
     const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
     float best_z = 0.f, bw0 = -1.f, bw1 = -1.f, bw2 = -1.f;
     int best_f = -1;
-    const float* fr = frec + (size_t)b * m.Ff * 9;
+    const float* fr = frec + (size_t)b * m.Ff * FREC_G;
     // NDC box of this wave's 8 x 8 block (NDC decreases with the pixel index): the same pix_to_ndc values its lanes use
-    const int lane = tid & 63, wx0 = tx0 + (tid >> 6) * 8;
+    const int wx0 = tx0 + (tid >> 6) * 8;
     const float sx_hi = pix_to_ndc(W - 1 - wx0, W), sx_lo = pix_to_ndc(W - 1 - (wx0 + 7), W);
     const float sy_hi = pix_to_ndc(H - 1 - ty0, H), sy_lo = pix_to_ndc(H - 1 - (ty0 + TILE_H - 1), H);
+    const float INF = __uint_as_float(0x7f800000u);
     for (int base = 0; base < n; base += FACE_CHUNK) {
         const int cnt = min(FACE_CHUNK, n - base);
-        __syncthreads();
+        // depth the block's pixels hold now: +inf while any of them is uncovered (pixels outside the image do not count).  It only falls as faces are
+        // visited, so a value read here stays a valid (conservative) bound for the whole chunk.
+        const float zblock = wave_max(!live ? -INF : (best_f >= 0 ? best_z : INF));
+        __syncthreads();                                          // the previous chunk's records and depth slots have been read by every wave
+        if (lane == 0) szmx[wave] = zblock;
         // stage one record per face: everything that does not depend on the pixel is computed ONCE here, with the same operations (and
         // -ffp-contract=off) the per-pixel code used, so every value is bit-identical: vertices, area + eps, the face's NDC box and the
         // (b - a) factors of the three edge functions
         if (tid < cnt) {
-            const int f = slist[base + tid];
-            const float* g = fr + (size_t)f * 9;
-            const float x0 = g[0], y0 = g[1], z0 = g[2], x1 = g[3], y1 = g[4], z1 = g[5], x2 = g[6], y2 = g[7], z2 = g[8];
+            const int i = base + tid;
+            const int s = i < n0 ? slist[i] : i < n1 ? slist[qmax + i - n0] : i < n2 ? slist[2 * qmax + i - n1] : slist[3 * qmax + i - n2];
+            const float4 g0 = *(const float4*)(fr + (size_t)s * FREC_G), g1 = *(const float4*)(fr + (size_t)s * FREC_G + 4),
+                         g2 = *(const float4*)(fr + (size_t)s * FREC_G + 8);
+            const float x0 = g0.x, y0 = g0.y, z0 = g0.z, x1 = g0.w, y1 = g1.x, z1 = g1.y, x2 = g1.z, y2 = g1.w, z2 = g2.x;
             float* r = sface + tid * FACE_REC;
             r[0] = x0; r[1] = y0; r[2] = z0; r[3] = x1; r[4] = y1; r[5] = z1; r[6] = x2; r[7] = y2; r[8] = z2;
             r[9] = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
@@ -195,9 +301,12 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
             r[14] = y2 - y1; r[15] = x2 - x1;                    // w0: edge_fn(p, v1, v2)
             r[16] = y0 - y2; r[17] = x0 - x2;                    // w1: edge_fn(p, v2, v0)
             r[18] = y1 - y0; r[19] = x1 - x0;                    // w2: edge_fn(p, v0, v1)
-            sfid[tid] = f;
+            r[20] = g2.y;                                        // zlow
+            sfid[tid] = __float_as_int(g2.z);
         }
         __syncthreads();
+        // every face from here on has zlow >= this chunk's first (ascending order): once all four blocks are covered in front of it the tile is done
+        if (fmaxf(fmaxf(szmx[0], szmx[1]), fmaxf(szmx[2], szmx[3])) < sface[20]) break;
         // wave-level cull: a wave owns an 8 x 8 pixel block; lane l tests face l of the chunk against the block's NDC box (64 faces in parallel,
         // one LDS read each) and only the faces that can touch the strip are walked.  Conservative w.r.t. the per-pixel box test below (a face
         // whose box misses the strip fails that test at every pixel of it), so the result is unchanged; it removes the serial
@@ -205,7 +314,7 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         bool rel = false;
         if (lane < cnt) {
             const float* r = sface + lane * FACE_REC;
-            rel = !(sx_lo > r[11] || sx_hi < r[10] || sy_lo > r[13] || sy_hi < r[12]);
+            rel = !(sx_lo > r[11] || sx_hi < r[10] || sy_lo > r[13] || sy_hi < r[12]) && !(r[20] > zblock);      // depth: see face_zlow
             // Edge test of the whole block (the synthetic FLAME basis stretches triangles to ~21 x 22-pixel boxes: a box overlaps many blocks its
             // triangle never enters).  A pixel is covered only if s e_k > 0 for all three edge functions, s = sign(area + eps); e_k is linear in the
             // pixel centre, so its maximum over the block sits at a corner and separates into an x and a y term.  The face is dropped when that
@@ -230,20 +339,22 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         while (relmask) {
             const int j = __builtin_ctzll(relmask);
             relmask &= relmask - 1;
-            const float* v = sface + j * FACE_REC;
-            if (xf > v[11] || xf < v[10] || yf > v[13] || yf < v[12]) continue;
-            const float x0 = v[0], y0 = v[1], x1 = v[3], y1 = v[4], x2 = v[6], y2 = v[7];
-            const float e0 = (xf - x1) * v[14] - (yf - y1) * v[15];
-            const float e1 = (xf - x2) * v[16] - (yf - y2) * v[17];
-            const float e2 = (xf - x0) * v[18] - (yf - y0) * v[19];
-            const float area = v[9];
+            // the whole record in six 16-byte broadcast reads, then straight-line arithmetic: the box test no longer costs four dependent LDS round trips
+            const float4* v4 = (const float4*)(sface + j * FACE_REC);
+            const float4 c0 = v4[0], c1 = v4[1], c2 = v4[2], c3 = v4[3], c4 = v4[4];
+            const float x0 = c0.x, y0 = c0.y, x1 = c0.w, y1 = c1.x, x2 = c1.z, y2 = c1.w;
+            const float area = c2.y;
+            const bool inbox = !(xf > c2.w || xf < c2.z || yf > c3.y || yf < c3.x);
+            const float e0 = (xf - x1) * c3.z - (yf - y1) * c3.w;
+            const float e1 = (xf - x2) * c4.x - (yf - y2) * c4.y;
+            const float e2 = (xf - x0) * c4.z - (yf - y0) * c4.w;
             // w_i = e_i / area > 0 needs e_i != 0 and sign(e_i) == sign(area): decided without the three divisions for the pixels of the box
             // that lie outside the triangle (area == 0 -> inf / NaN quotients: left to the exact path)
-            if (area != 0.0f && (e0 == 0.0f || (e0 < 0.0f) != (area < 0.0f) || e1 == 0.0f || (e1 < 0.0f) != (area < 0.0f) || e2 == 0.0f ||
-                                 (e2 < 0.0f) != (area < 0.0f)))
-                continue;
+            const bool neg = area < 0.0f;
+            const bool out = area != 0.0f && (e0 == 0.0f || (e0 < 0.0f) != neg || e1 == 0.0f || (e1 < 0.0f) != neg || e2 == 0.0f || (e2 < 0.0f) != neg);
+            if (!inbox || out) continue;
             const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
-            const float pz = w0 * v[2] + w1 * v[5] + w2 * v[8];
+            const float pz = w0 * c0.z + w1 * c1.y + w2 * c2.x;
             if (pz < 0) continue;
             if (!((w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f))) continue;
             const int f = sfid[j];
@@ -292,13 +403,14 @@ static MeshDev mesh_dev(const SmirkRenderMesh* m) {
 }
 
 static size_t ws_normals(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Vf * 12, 256); }
-static size_t ws_frec(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Ff * 36, 256); }
+static size_t ws_frec(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Ff * FREC_G * 4, 256); }
 static size_t ws_fbox(const SmirkRenderMesh* m, int B) { return smirk_align_up((size_t)B * m->Ff * 8, 256); }
+static size_t ws_nvalid(int B) { return smirk_align_up((size_t)B * 4, 256); }
 
 extern "C" size_t smirk_render_workspace_bytes(const SmirkRenderMesh* mesh, int B, int H, int W) {
     if (!mesh || B <= 0) return 0;
     (void)H; (void)W;
-    return ws_normals(mesh, B) + ws_frec(mesh, B) + ws_fbox(mesh, B);
+    return ws_normals(mesh, B) + ws_frec(mesh, B) + ws_fbox(mesh, B) + ws_nvalid(B);
 }
 
 extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, int W, const float* verts,
@@ -312,24 +424,28 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
     char* p = (char*)ws;
     float* nrm = (float*)p; p += ws_normals(mesh, B);
     float* frec = (float*)p; p += ws_frec(mesh, B);
-    short4* fbox = (short4*)p;
+    short4* fbox = (short4*)p; p += ws_fbox(mesh, B);
+    int* nvalid = (int*)p;
     if (normals) nrm = normals;
     const size_t nv = (size_t)B * mesh->V, nk = (size_t)B * mesh->Vf, nf = (size_t)B * mesh->Ff;
     SMIRK_LAUNCH(render_project, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam, B, mesh->V,
                        transformed);
     SMIRK_LAUNCH(render_normals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, d, B, verts, nrm);
-    SMIRK_LAUNCH(raster_face_setup, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, transformed,
-                       frec, fbox);
+    if (mesh->Ff <= SORT_N)
+        SMIRK_LAUNCH(raster_face_setup_sorted, dim3((unsigned)B), dim3(512), 0, st, d, B, H, W, transformed, frec, fbox, nvalid);
+    else
+        SMIRK_LAUNCH(raster_face_setup, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d, B, H, W, transformed, frec, fbox, nvalid);
     const int tiles = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-    const size_t smem = FACE_CHUNK * FACE_REC * 4 + FACE_CHUNK * 4 + 16 + smirk_align_up((size_t)mesh->Ff * 2, 16);
+    const int qmax = (((mesh->Ff + 3) / 4 + 63) & ~63) + 8;          // capacity of a wave's binned list (a quarter of the faces, whole 64-face rounds)
+    const size_t smem = FACE_CHUNK * FACE_REC * 4 + FACE_CHUNK * 4 + 32 + smirk_align_up((size_t)4 * qmax * 2, 16);
 #ifdef SMIRK_DEBUG_HOOKS                                            /* -DSMIRK_DEBUG_HOOKS variant builds only (tools/build_variant.sh, tools/raster_time.py) */
     static const char* abl = getenv("SMIRK_RASTER_ABLATE");      // 1: no per-pixel face loop, 2: no binning scan (timing experiments; wrong images)
     const int ablate = abl ? atoi(abl) : 0;
 #else
     const int ablate = 0;
 #endif
-    SMIRK_LAUNCH(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nrm, img,
-                       (long long*)pix_to_face, bary, zbuf, ablate);
+    SMIRK_LAUNCH(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nvalid, nrm, img,
+                       (long long*)pix_to_face, bary, zbuf, qmax, ablate);
     return smirk_launch_status();
 }
 
