@@ -746,6 +746,10 @@ def run_also(args, dev, L):
             wl.drain(); torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             assert_finite(wl.last, wl.keys, f"also/{name} after the timed steps")
+            te = time.perf_counter()                        # host time to enqueue one step into the now empty queue
+            wl.step()
+            t_enq = time.perf_counter() - te
+            wl.drain(); torch.cuda.synchronize()
             L.profile_start()
             wl.instrumented(); wl.drain(); torch.cuda.synchronize()
             recs = L.profile_stop()
@@ -754,7 +758,7 @@ def run_also(args, dev, L):
                  "frames_per_step": wl.B,
                  "dtype": ("f16 products, f32 accumulate (one fp16 MFMA per product block)" if over.get("train_arith") == "f16x1" else
                            "f32 (fp32 MFMA)" if a.workload == "flame512" else "f32-class (split-fp16 x3 MFMA, f32 accumulate)"),
-                 "launches_per_step": len(recs)}
+                 "launches_per_step": len(recs), "host_enqueue_ms_one_step_idle_queue": t_enq * 1e3}
             if roof is not None:
                 e["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_pass", "avg_launch_ms",
                                                           "profiled_kernel_ms_per_pass")}

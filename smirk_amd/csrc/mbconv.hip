@@ -294,15 +294,17 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
     }
     // ---- epilogue: bn3 -> LDS (re-using Es) -> (+ residual) -> split16 stores ---------------------------------------------------------
     float* Os = Es;
+    // the lane id is re-derived (mbcnt) for the epilogue: <1, true, 3> kept a lane-derived value alive across the chunk loop in scratch otherwise
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 #pragma unroll
     for (int q = 0; q < P3; ++q) {
         const int id = wave + 4 * q;
         if (id < ntiles) {
-            const int mt = id / ntn, nt = id - mt * ntn, co = nt * 32 + fr;
+            const int mt = id / ntn, nt = id - mt * ntn, co = nt * 32 + (lane_e & 31);
             const float s3 = co < a.Cout ? a.s3[co] : 0.f, b3 = co < a.Cout ? a.b3[co] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + mfma32_row(r, lane);
+                const int row = mt * 32 + mfma32_row(r, lane_e);
                 Os[row * a.coutp + co] = (pacc[q][0][r] + pacc[q][1][r] * (1.0f / 2048.0f)) * s3 + b3;
             }
         }

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
     const int nchunks = (a.mid + 31) / 32;
     const size_t xrow = (size_t)a.Cin * 4;
     const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool active = wave < a.nb;                    // one 32-row block per wave
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const bool active = swave < a.nb;                   // one 32-row block per wave
     const int wpbuf = a.Cout * 144;
 
     // ---- prefetch helpers ----------------------------------------------------------------------------------------------------------------------------
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
                         const f32x4 w0 = *(const f32x4*)(wc + (ky * 3 + kx) * 32 + c8), w1 = *(const f32x4*)(wc + (ky * 3 + kx) * 32 + c8 + 4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { acc[q] = fmaf(v0[q], w0[q], acc[q]); acc[4 + q] = fmaf(v1[q], w1[q], acc[4 + q]); }
-                        if (kx == 2) __builtin_amdgcn_sched_barrier(0);   // at most one tap row (12 ds_read_b128 = 48 registers) in flight beside the 128 accumulators
+                        if (kx == 2 || NT == 4) __builtin_amdgcn_sched_barrier(0);   // at most one tap row (12 ds_read_b128 = 48 registers; NT = 4: one tap, 16) in flight beside the 128 accumulators
                     }
                 const f32x4 sa = *(const f32x4*)(wc + 9 * 32 + c8), sb = *(const f32x4*)(wc + 9 * 32 + c8 + 4);
                 const f32x4 ba = *(const f32x4*)(wc + 10 * 32 + c8), bb = *(const f32x4*)(wc + 10 * 32 + c8 + 4);
@@ -262,6 +263,9 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
 
     // ---- epilogue: bn3 (+ x), per-wave 32 x 32 transposes through the (now free) grid region, split16 stores ---------------------------------------------
     if (active) {
+        // lane / wave are re-derived (mbcnt, the wave id kept in an SGPR since the prologue): at NT = 4 the thread-id register was the one value that did not fit
+        // beside the accumulators across the chunk loop and went to scratch
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wave = swave, fr = lane & 31;
         float* tb = Es + wave * (32 * 36);              // 32 rows x 36 floats per wave: 7 x 4608 B <= the 32 KB grid
         char* ob = a.out + (size_t)b0 * HW * a.Cout * 4;
 #pragma unroll

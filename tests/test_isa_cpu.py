@@ -80,3 +80,16 @@ def test_design_instructions_present(isa):
 def test_fused_maxpool_kernel_is_in_the_library(isa):
     names = [k for k in isa if "maxpool_sq_lds_kernel" in k]
     assert len(names) == 2, names                              # R = 10 (masking.py:78) and R = 5 (masking.py:96)
+
+
+def test_no_scratch_memory_in_any_kernel(isa):
+    """No kernel of the library touches scratch (private) memory: a register spill inside a chunk loop is a global-memory round trip per iteration, and the
+    register-bound fused encoder kernels (mbconv_image_kernel<7,4> / <6,4> / <5,4> / <7,3>, mbconv_fused_kernel<1,true,3>) shipped with 3-34 scratch instructions
+    through round 4.  Their loop-invariant address arithmetic is now re-derived per chunk behind `asm volatile` fences and the epilogues re-derive the
+    lane / wave ids (mbcnt, an SGPR copy) instead of keeping the thread id alive across the loop."""
+    bad = {}
+    for name, ins in isa.items():
+        n = sum(1 for i in ins if re.match(r"scratch_(load|store)", i))
+        if n:
+            bad[name] = n
+    assert not bad, f"kernels with scratch traffic: {bad}"
