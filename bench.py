@@ -682,7 +682,7 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
                 "note": "achieved = algorithmic bytes (unique operands in + out) per launch / HIP-event launch time" if by else
                         "the dispatcher states no algorithmic byte count for this kernel"}
     roof["rocprofv3"] = rocprofv3_avg(workload, dom)
-    roof.update(launches_per_pass=n, avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
+    roof.update(launches_per_pass=n, launches_total_per_pass=sum(v[3] for v in per.values()), avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
                 kernel_name_source="libsmirk_hip.so launch profiler (smirk_profile_start/stop): the instantiation that was launched, HIP events on its launch stream",
                 kernels={k: {"ms_per_pass": round(v[2] * 1e3, 4), "launches": v[3], **({"tflops": round(v[0] / v[2] / 1e12, 2)} if v[0] > 0 else {}),
                              **({"gbps": round(v[1] / v[2] / 1e9, 1)} if v[1] > 0 else {})} for k, v in sorted(per.items(), key=lambda t: -t[1][2])[:28]},
@@ -692,91 +692,47 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
 # ------------------------------------------------------------------------------------------------------------------------------
 # "also": the other BASELINE configs, timed in the same process AFTER the headline's timed region (the driver only ever runs `bench.py --gpus 1`)
 # ------------------------------------------------------------------------------------------------------------------------------
-ALSO_SPECS = (   # name, argv overrides, steps, warmup
-    ("flame512", dict(workload="flame512"), 50, 10),
-    ("infer256", dict(workload="infer256"), 10, 3),
-    ("train64_f16x3", dict(workload="train64", train_arith="f16x3"), 6, 3),
-    ("train64_f16x1", dict(workload="train64", train_arith="f16x1"), 6, 3),
-    ("full_shard128_collective", dict(workload="full", global_batch=128, force_collective=True), 10, 3),
+ALSO_SPECS = (   # name, argv of the child run, steps, warmup
+    ("flame512", ["--workload", "flame512"], 50, 10),
+    ("infer256", ["--workload", "infer256"], 20, 5),
+    ("train64_f16x3", ["--workload", "train64", "--train-arith", "f16x3"], 10, 3),
+    ("train64_f16x1", ["--workload", "train64", "--train-arith", "f16x1"], 10, 3),
+    ("full_shard128_collective", ["--workload", "full", "--global-batch", "128", "--force-collective"], 20, 5),
 )
 
 
-def run_also(args, dev, L):
-    """Short timed regions of BASELINE configs 2, 3, 5 (both training arithmetics) and of the per-rank shard of the 8-GPU job (128 frames, the asynchronous
-    all-gather really enqueued through a world-size-1 RCCL group).  Same step()/drain()/synchronize bracketing as the headline, same workload classes as
-    `--workload X`; each entry carries the roofline fraction of ITS dominant kernel (launch profiler, one instrumented pass; no counter passes).  Runs after
-    the headline's timed region and touches none of its fields; an entry that fails reports its error instead of taking the line down."""
-    import copy
-    import gc
-    import torch
-    import torch.distributed as dist
+def run_also(args):
+    """BASELINE configs 2, 3, 5 (both training arithmetics) and the per-rank shard of the 8-GPU job (128 frames, the asynchronous all-gather really enqueued through
+    a world-size-1 RCCL group), each as its OWN `python bench.py --workload ...` process started after the headline's timed region: exactly the command a builder
+    would run by hand, so the numbers are the stand-alone numbers.  (Round 5 first ran them inside this process: after the 1024-frame headline had been through the
+    allocator every streaming kernel of the later workloads ran at ~0.65 of its stand-alone rate — train64 67.5 ms in-process against 43.6 ms alone on the same box,
+    infer256 38.8 k against 43.5 k, profiles/r05b_* — so the in-process numbers described the bench process, not the library.)  Each child computes its own roofline
+    from the launch profiler (no counter passes, no CPU baseline); an entry that fails reports the error instead of taking the headline down."""
     out, t_all = {}, time.perf_counter()
-    cache = {}
-    for name, over, steps, warmup in ALSO_SPECS:
+    for name, argv, steps, warmup in ALSO_SPECS:
         t_entry = time.perf_counter()
-        a = copy.copy(args)
-        a.global_batch = a.batch = None
-        a.force_collective = False
-        a.micro_batch = MICRO_BATCH
-        for k, v in over.items():
-            setattr(a, k, v)
-        own_group, wl = False, None
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", "0", "--no-also",
+                                                                    "--flame-basis", args.flame_basis]
         try:
-            if a.force_collective and not dist.is_initialized():
-                s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
-                dist.init_process_group(a.backend, init_method=f"tcp://127.0.0.1:{port_}", rank=0, world_size=1, device_id=dev)
-                own_group = True
-            sb = tempfile.mkdtemp(prefix=f"smirk_also_{name}_")
-            if a.workload == "train64" and "train64" in cache:          # the second arithmetic re-uses the modules, inputs and optimiser state
-                wl = cache["train64"]
-                from smirk_amd.cycle import set_train_arith
-                set_train_arith(wl.gen, wl.enc, a.train_arith)
-            else:
-                cls = {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload, "train64": TrainWorkload}[a.workload]
-                wl = cls(a, dev, 0, 1, sb)
-                if a.workload == "train64":
-                    cache["train64"] = wl
-            for _ in range(warmup):
-                wl.step()
-            wl.drain(); torch.cuda.synchronize()
-            assert_finite(wl.last, wl.keys, f"also/{name} after warm-up")
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                wl.step()
-            wl.drain(); torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            assert_finite(wl.last, wl.keys, f"also/{name} after the timed steps")
-            te = time.perf_counter()                        # host time to enqueue one step into the now empty queue
-            wl.step()
-            t_enq = time.perf_counter() - te
-            wl.drain(); torch.cuda.synchronize()
-            L.profile_start()
-            wl.instrumented(); wl.drain(); torch.cuda.synchronize()
-            recs = L.profile_stop()
-            roof = roofline_from_records(recs, a.workload, None, "not collected (also-entry)", dt / steps)
-            e = {"metric": METRIC[a.workload], "value": wl.B * steps / dt, "unit": "faces/sec", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-                 "frames_per_step": wl.B,
-                 "dtype": ("f16 products, f32 accumulate (one fp16 MFMA per product block)" if over.get("train_arith") == "f16x1" else
-                           "f32 (fp32 MFMA)" if a.workload == "flame512" else "f32-class (split-fp16 x3 MFMA, f32 accumulate)"),
-                 "launches_per_step": len(recs), "host_enqueue_ms_one_step_idle_queue": t_enq * 1e3}
-            if roof is not None:
-                e["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_pass", "avg_launch_ms",
-                                                          "profiled_kernel_ms_per_pass")}
-            if a.workload == "train64":
-                e["loss"] = float(wl.last["loss"])
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, cwd=REPO)
+            lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc={r.returncode}: {r.stderr.decode(errors='replace')[-300:]}")
+            j = json.loads(lines[-1])
+            roof = j.get("roofline") or {}
+            e = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+                 "frames_per_step": j["config"]["frames_per_gpu_per_step"], "dtype": j["dtype"], "command": "python bench.py " + " ".join(cmd[2:]),
+                 "host_enqueue_ms_one_step_idle_queue": j.get("host_enqueue_ms_one_step_idle_queue"),
+                 "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_pass", "avg_launch_ms",
+                                                       "profiled_kernel_ms_per_pass")},
+                 "launches_per_step": roof.get("launches_total_per_pass")}
             out[name] = e
         except Exception as ex:                     # noqa: BLE001 — the headline line must still be produced
-            out[name] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
-        finally:
-            if own_group and dist.is_initialized():
-                dist.destroy_process_group()
-            if a.workload != "train64":
-                wl = None
-            gc.collect(); torch.cuda.empty_cache()
+            out[name] = {"error": f"{type(ex).__name__}: {str(ex)[:400]}"}
         out[name]["wall_s"] = round(time.perf_counter() - t_entry, 2)
-    cache.clear(); gc.collect(); torch.cuda.empty_cache()
-    out["_note"] = ("timed in this process after the headline's timed region, inputs resident, same step/drain/synchronize bracketing; builder-side full-length "
-                    "lines of the same workloads are under profiles/; total wall %.1f s" % (time.perf_counter() - t_all))
+    out["_note"] = ("each entry is a separate `python bench.py --workload ...` process run after the headline's timed region (inputs resident, same step / drain / "
+                    "synchronize bracketing, roofline from the launch profiler); full-length builder-side lines of the same commands are under profiles/; total "
+                    "wall %.1f s" % (time.perf_counter() - t_all))
     return out
 
 
@@ -914,7 +870,7 @@ def main():
         wl = wl_keep                          # release the headline's modules and its ~64 GB of activations before the other configs run
         import gc
         gc.collect(); torch.cuda.empty_cache()
-        also = run_also(args, dev, L)
+        also = run_also(args)
     if rank == 0:
         B = wl.B
         faces = B * world * args.steps

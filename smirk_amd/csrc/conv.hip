@@ -631,7 +631,7 @@ int smirk_conv_pp_launch(const ConvArgs& a, hipStream_t st);
 
 // conv_halo.hip: the ping-pong schedule with the A operand staged once per channel chunk (one pixel halo serves all nine taps)
 bool smirk_conv_halo_eligible(const ConvArgs& a);
-int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st);
+int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st, bool x1);
 
 // conv_patch.hip: persistent halo-patch kernel for the large-image / few-channel 3x3 layers (split-fp16 only)
 bool smirk_conv3x3_patch_eligible(const SmirkConvDesc* d, bool has_residual);
@@ -708,7 +708,7 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
         return smirk_conv3x3_ring64_launch(d, in0, in1, w, scale, shift, out, nullptr, st);
     if (split && !x1 && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
-    if (split && !x1 && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st);
+    if (split && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st, x1);      // (the halo kernel has an X1 instantiation: conv_halo_x1_kernel)
     if (split && !x1 && smirk_conv_pp_eligible(a)) return smirk_conv_pp_launch(a, st);
     if (split && x1) {                                           // F16X1: the same three tile shapes, one MFMA per block
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true, true>(a, st);

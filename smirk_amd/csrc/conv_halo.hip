@@ -61,8 +61,10 @@ __device__ __forceinline__ int hs_b_off(int row, int stage, int piece) {
 //      (tools/halo_timeline.py) shows the matrix pipe idle for ~130 cycles at every hand-over: the finishing wave reaches the barrier, the barrier
 //      releases, the partner wakes up and issues its first MFMA.  With the barrier placed EB MFMAs before the end, the finishing wave's tail keeps the
 //      pipe busy while the partner wakes up.  Nothing the barrier orders depends on the position of a wave's MFMAs (they only touch registers).
-template <int NPA, int EB>
-__global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
+// X1:  one fp16 MFMA per product block on the hi halves only (the training path's "f16x1" arithmetic, generator_train.TRAIN_ARITH): the lo fragments are neither
+//      read from LDS nor multiplied — 8 of the 24 MFMAs and 8 of the 16 fragment reads of a chunk remain.  Same K order as conv_igemm_kernel's X1 instantiation.
+template <int NPA, int EB, bool X1>
+__device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
     constexpr int NL = 3;   // DMA instructions issued in the load phase: 1-3 measured equal, 0 (all among the MFMAs) 2-3 % slower (profiles/r03b_halo_nl_sweep.txt)
     extern __shared__ __attribute__((aligned(16))) float hs_smem[];
     char* lds = (char*)hs_smem;
@@ -156,15 +158,23 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
         {
             const unsigned t = tabA[TAP];
             const unsigned a0 = (t & 0xffffu) + (unsigned)acur, a1 = (t >> 16) + (unsigned)acur;
-            ah[0][0] = *(const half8*)(lds + a0);        al[0][0] = *(const half8*)(lds + (a0 ^ 16u));
-            ah[1][0] = *(const half8*)(lds + (a0 ^ 64u)); al[1][0] = *(const half8*)(lds + (a0 ^ 80u));
-            ah[0][1] = *(const half8*)(lds + a1);        al[0][1] = *(const half8*)(lds + (a1 ^ 16u));
-            ah[1][1] = *(const half8*)(lds + (a1 ^ 64u)); al[1][1] = *(const half8*)(lds + (a1 ^ 80u));
+            ah[0][0] = *(const half8*)(lds + a0);
+            ah[1][0] = *(const half8*)(lds + (a0 ^ 64u));
+            ah[0][1] = *(const half8*)(lds + a1);
+            ah[1][1] = *(const half8*)(lds + (a1 ^ 64u));
+            if constexpr (!X1) {
+                al[0][0] = *(const half8*)(lds + (a0 ^ 16u)); al[1][0] = *(const half8*)(lds + (a0 ^ 80u));
+                al[0][1] = *(const half8*)(lds + (a1 ^ 16u)); al[1][1] = *(const half8*)(lds + (a1 ^ 80u));
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const unsigned b0 = bB[j];
-                bh[0][j] = *(const half8*)(lds + b0 + ST * 1024);          bl[0][j] = *(const half8*)(lds + (b0 ^ 16u) + ST * 1024);
-                bh[1][j] = *(const half8*)(lds + (b0 ^ 64u) + ST * 1024);  bl[1][j] = *(const half8*)(lds + (b0 ^ 80u) + ST * 1024);
+                bh[0][j] = *(const half8*)(lds + b0 + ST * 1024);
+                bh[1][j] = *(const half8*)(lds + (b0 ^ 64u) + ST * 1024);
+                if constexpr (!X1) {
+                    bl[0][j] = *(const half8*)(lds + (b0 ^ 16u) + ST * 1024);
+                    bl[1][j] = *(const half8*)(lds + (b0 ^ 80u) + ST * 1024);
+                }
             }
         }
         // this phase pair's DMA list: [halo piece TAP of the NEXT channel chunk (taps 0 .. NPA-1),] the two weight pieces of the chunk two ahead.  Past
@@ -209,11 +219,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if constexpr (BK == 0) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], acc0[i][j], 0, 0, 0);
-                    if constexpr (BK == 1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], acc1[i][j], 0, 0, 0);
-                    if constexpr (BK == 2) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 1 && !X1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 2 && !X1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], acc1[i][j], 0, 0, 0);
                     if constexpr (BK == 3) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], acc0[i][j], 0, 0, 0);
-                    if constexpr (BK == 4) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], acc1[i][j], 0, 0, 0);
-                    if constexpr (BK == 5) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 4 && !X1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], acc1[i][j], 0, 0, 0);
+                    if constexpr (BK == 5 && !X1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], acc1[i][j], 0, 0, 0);
                 }
         };
         auto hand_over = [&]() {                                     // the barrier that ends the matrix phase
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ebuf[mfma32_row(r, lane) * HS_EPI_LD + j * 32 + fr] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+            for (int r = 0; r < 16; ++r) ebuf[mfma32_row(r, lane) * HS_EPI_LD + j * 32 + fr] = X1 ? acc0[i][j][r] : acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -366,6 +376,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) {
 #endif
 }
 
+template <int NPA, int EB>
+__global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) { conv_halo_body<NPA, EB, false>(a); }
+template <int NPA>
+__global__ __launch_bounds__(512, 2) void conv_halo_x1_kernel(ConvArgs a) { conv_halo_body<NPA, 0, true>(a); }
+
 static int hs_env_mode() {                                           // $SMIRK_IGEMM_HALO: "0" off; unset / anything else = every eligible geometry
     const char* env = getenv("SMIRK_IGEMM_HALO");                   // read per call: tests toggle it
     return !env ? 1 : env[0] == '0' ? 0 : env[0] == 'a' ? 2 : 1;
@@ -392,11 +407,12 @@ bool smirk_conv_halo_eligible(const ConvArgs& a) {
     return true;
 }
 
-template <int NPA, int EB>
+template <int NPA, int EB, bool X1>
 static int hs_launch(const ConvArgs& a, hipStream_t st, size_t lds, int dev) {
     static bool attr_done[64] = {};                                  // hipFuncSetAttribute is per-device state (one process may drive several GPUs)
+    const void* fn = X1 ? (const void*)conv_halo_x1_kernel<NPA> : (const void*)conv_halo_kernel<NPA, EB>;
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<NPA, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SMIRK_ERR_LAUNCH;
         attr_done[dev] = true;
     }
@@ -404,15 +420,17 @@ static int hs_launch(const ConvArgs& a, hipStream_t st, size_t lds, int dev) {
     if (g_smirk_prof_on) {
         const double px = (double)a.d.B * a.d.H * a.d.W;
         char nm[64];
-        snprintf(nm, sizeof(nm), "conv_halo_kernel<%d,%d>[256x128,8w,halo]", NPA, EB);
+        if (X1) snprintf(nm, sizeof(nm), "conv_halo_x1_kernel<%d>[256x128,8w,halo,f16x1]", NPA);
+        else snprintf(nm, sizeof(nm), "conv_halo_kernel<%d,%d>[256x128,8w,halo]", NPA, EB);
         smirk_prof_next(nm, 2.0 * a.M * a.N * a.K,
                         4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
     }
-    SMIRK_LAUNCH((conv_halo_kernel<NPA, EB>), dim3(ntm * ntn), dim3(512), lds, st, a);
+    if constexpr (X1) SMIRK_LAUNCH((conv_halo_x1_kernel<NPA>), dim3(ntm * ntn), dim3(512), lds, st, a);
+    else SMIRK_LAUNCH((conv_halo_kernel<NPA, EB>), dim3(ntm * ntn), dim3(512), lds, st, a);
     return smirk_launch_status();
 }
 
-int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st) {
+int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st, bool x1) {
     const int npa = (HS_BM + 2 * (a.d.W + 1) + 63) / 64;             // 64 halo rows per piece index (8 waves x 8 rows)
     const size_t lds = HS_BRING_BYTES + 2 * ((size_t)(npa <= 5 ? 5 : 6) * 8 * 1024 + 128) + HS_DBG_LDS;
 #ifdef SMIRK_DEBUG_HOOKS
@@ -427,5 +445,6 @@ int smirk_conv_halo_launch(const ConvArgs& a, hipStream_t st) {
     if (dev < 0 || dev >= 64) return SMIRK_ERR_UNSUPPORTED;
     // (EB = MFMAs issued after the hand-over barrier: 4 / 8 measured 3-7 % slower without the time stamps in, profiles/r03b_halo_nl_sweep.txt, r04x_kernel_selection.txt;
     // the $SMIRK_HALO_EB switch and its instantiations left the library in round 5)
-    return npa <= 5 ? hs_launch<5, HS_DEFAULT_EB>(a, st, lds, dev) : hs_launch<6, HS_DEFAULT_EB>(a, st, lds, dev);
+    if (x1) return npa <= 5 ? hs_launch<5, HS_DEFAULT_EB, true>(a, st, lds, dev) : hs_launch<6, HS_DEFAULT_EB, true>(a, st, lds, dev);
+    return npa <= 5 ? hs_launch<5, HS_DEFAULT_EB, false>(a, st, lds, dev) : hs_launch<6, HS_DEFAULT_EB, false>(a, st, lds, dev);
 }
