@@ -455,6 +455,16 @@ int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H,
  * SMIRK_ERR_UNSUPPORTED when the fp16 weight-gradient kernels do not serve the call (operands of 2 GiB and more, $SMIRK_WGRAD_F16=0). */
 int smirk_conv_wgrad_f16x1(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                            void* stream);
+/* the same weight gradient summed straight into the layout the caller keeps it in — what autograd hands the optimiser for `conv.weight.grad`
+ * (smirk_trainer.py:367-376 backward + Adam; nn.Conv2d / nn.ConvTranspose2d parameter layouts), so no permute-copy / torch.cat follows:
+ *   layout 0  packed [Cout][(ky,kx,ci)] (as smirk_conv_wgrad_f32)
+ *   layout 1  nn.Conv2d weight [Cout][cin_total][KH][KH], channels [cin_off, cin_off + cin_real) — cin_real <= Cin drops padded operand channels, and the two
+ *             sources of a decoder convolution (torch.cat((up, skip), 1), smirk_generator.py:65-75) fill the two channel ranges of ONE tensor in two calls
+ *   layout 2  nn.ConvTranspose2d(Cout, Cin / 4, 2, 2) weight [Cout][Cin / 4][2][2] from the 1x1 form of its backward (dz = the layer's input, x = space-to-depth of
+ *             the output gradient; KH = 1)
+ * x1 != 0 asks for the f16x1 arithmetic where the fp16 kernels serve the call (falls back to the f32-class kernels otherwise, like the Python caller did). */
+int smirk_conv_wgrad_param(const void* dz, const void* x, float* dw_param, int B, int H, int W, int Cout, int Cin, int KH, int reflect, int layout, int cin_total,
+                           int cin_off, int cin_real, int x1, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- train-mode SmirkEncoder backbones (csrc/train_encoder.hip): what `self.train()` + autograd does to the timm
  * tf_mobilenetv3_{small,large}_minimal_100 feature extractors of smirk_encoder.py:7-12 (pointwise convolutions and BatchNorm reuse the entries above).

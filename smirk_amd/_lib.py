@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
-ABI_VERSION = 9
+ABI_VERSION = 10
 SMIRK_OK, SMIRK_ERR_BAD_ARG, SMIRK_ERR_WORKSPACE, SMIRK_ERR_LAUNCH, SMIRK_ERR_UNSUPPORTED = 0, -1, -2, -3, -4      # include/smirk_hip.h
 
 _p = C.c_void_p
@@ -150,6 +150,7 @@ _SIGS = {
     "smirk_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_conv_wgrad_f16x1": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_conv_wgrad_param": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_pack_conv_weights_batch_split16": (_i, [_p, _i, C.c_ulonglong, _p]),
     "smirk_pack_conv_weights_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_stem_conv_s2_raw_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

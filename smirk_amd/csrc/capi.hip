@@ -12,7 +12,7 @@ extern "C" const char* smirk_strerror(int code) {
     }
 }
 
-extern "C" int smirk_abi_version(void) { return 9; }
+extern "C" int smirk_abi_version(void) { return 10; }
 
 // ---- launch profiler ---------------------------------------------------------------------------------------------------------------
 #include <mutex>

@@ -939,7 +939,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ dw) {
+// Sum of the split-K partials, written in the layout the CALLER keeps the gradient in (no permute-copy / torch.cat afterwards):
+//   layout 0  packed  dw[co][(t, ci)]                                   (the forward operand layout; what the kernels above accumulate)
+//   layout 1  nn.Conv2d parameter  dw[co][cin_off + ci][t]  of a [Cout][cin_total][KH][KH] tensor, ci < cin_real (padded input channels are dropped; the two
+//             sources of a decoder convolution write the two channel ranges of ONE gradient tensor)
+//   layout 2  nn.ConvTranspose2d(2, 2) parameter  dw[row][co][dydx]  of a [Cin_t][Cout_t][2][2] tensor, from the packed [row][(dydx, co)] (row = input channel)
+struct WgradLayout { int mode, T, Cin, cin_total, cin_off, cin_real; };
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ dw, WgradLayout L) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // 8 independent chains keep 8 loads in flight; combined in a fixed order
         int k = 0;
@@ -947,7 +953,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += part[(size_t)(k + j) * n + i];
         for (; k < nsplit; ++k) s[0] += part[(size_t)k * n + i];
-        dw[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        if (L.mode == 0) {
+            dw[i] = v;
+        } else if (L.mode == 1) {
+            const int N = L.T * L.Cin;
+            const size_t co = i / (size_t)N;
+            const int rem = (int)(i - co * N), t = rem / L.Cin, ci = rem - t * L.Cin;
+            if (ci < L.cin_real) dw[((size_t)co * L.cin_total + L.cin_off + ci) * L.T + t] = v;
+        } else {
+            const int N = L.Cin;                                          // = 4 * Cout_t columns (dydx, co)
+            const size_t row = i / (size_t)N;
+            const int rem = (int)(i - row * N), ct = N / 4, dydx = rem / ct, co = rem - dydx * ct;
+            dw[((size_t)row * ct + co) * 4 + dydx] = v;
+        }
     }
 }
 
@@ -1178,7 +1197,7 @@ extern "C" size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout
 }
 /* dW[Cout][(ky,kx,ci)] (fp32, the packed forward layout) = sum over pixels of dz[p][co] * x[p + tap][ci];  KH in {1, 3}, pad = (KH-1)/2 */
 static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
-                           void* stream, int x1);
+                           void* stream, int x1, WgradLayout L = WgradLayout{0, 0, 0, 0, 0, 0});
 extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                                     void* stream) {
     return conv_wgrad_impl(dz, x, dw, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 0);
@@ -1189,8 +1208,25 @@ extern "C" int smirk_conv_wgrad_f16x1(const void* dz, const void* x, float* dw, 
                                       void* stream) {
     return conv_wgrad_impl(dz, x, dw, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 1);
 }
+/* The weight gradient summed straight into the PARAMETER's layout (WgradLayout above): layout 1 = nn.Conv2d weight [Cout][cin_total][KH][KH], channels
+ * [cin_off, cin_off + cin_real) (Cin - cin_real padded operand channels are dropped); layout 2 = nn.ConvTranspose2d(2, 2) weight [Cout][Cin / 4][2][2] from the
+ * 1x1 form the ConvTranspose backward uses (dz = the layer's INPUT, x = space-to-depth of the output gradient).  x1 != 0: one MFMA per product block. */
+extern "C" int smirk_conv_wgrad_param(const void* dz, const void* x, float* dw_param, int B, int H, int W, int Cout, int Cin, int KH, int reflect, int layout,
+                                      int cin_total, int cin_off, int cin_real, int x1, void* ws, size_t ws_bytes, void* stream) {
+    if (layout == 1) {
+        if (cin_real <= 0 || cin_real > Cin || cin_off < 0 || cin_off + cin_real > cin_total) return SMIRK_ERR_BAD_ARG;
+    } else if (layout == 2) {
+        if (KH != 1 || Cin % 4) return SMIRK_ERR_BAD_ARG;
+    } else if (layout != 0) {
+        return SMIRK_ERR_BAD_ARG;
+    }
+    const WgradLayout L{layout, KH * KH, Cin, cin_total, cin_off, cin_real};
+    int rc = x1 ? conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 1, L) : SMIRK_ERR_UNSUPPORTED;
+    if (rc == SMIRK_ERR_UNSUPPORTED) rc = conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 0, L);
+    return rc;
+}
 static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
-                           void* stream, int x1) {
+                           void* stream, int x1, WgradLayout L) {
     if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || Cout % 8 || Cin % 8 || Cout <= 0 || Cin <= 0 || (KH != 1 && KH != 3)) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH)) return SMIRK_ERR_WORKSPACE;
     const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
@@ -1221,7 +1257,7 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 64>), dim3(nsplit), dim3(256), 0, hs, h);
         else SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 64>), dim3(nsplit), dim3(256), 0, hs, h);
         const size_t nh = (size_t)Cout * N;
-        SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(nh, 4096)), dim3(256), 0, hs, (const float*)ws, nsplit, nh, dw);
+        SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(nh, 4096)), dim3(256), 0, hs, (const float*)ws, nsplit, nh, dw, L);
         return smirk_launch_status();
     }
     WgradArgs a;
@@ -1255,6 +1291,6 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
     else if (TM == 64) SMIRK_LAUNCH(wgrad_kernel<64>, grid, dim3(256), 0, st, a);
     else SMIRK_LAUNCH(wgrad_kernel<128>, grid, dim3(256), 0, st, a);
     const size_t n = (size_t)Cout * KH * KH * Cin;
-    SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, st, (const float*)ws, nsplit, n, dw);
+    SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, st, (const float*)ws, nsplit, n, dw, L);
     return smirk_launch_status();
 }

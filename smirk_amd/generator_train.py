@@ -150,6 +150,18 @@ class _Ops:
         L.check(rc)
         return dw
 
+    def wgrad_param(self, dz, x, B, H, W, cout, cin, k, out, layout=1, cin_off=0, cin_real=None, reflect=False):
+        """weight gradient summed straight into `out`, a tensor in the PARAMETER's layout (smirk_conv_wgrad_param): nn.Conv2d weight [cout][cin_total][k][k],
+        channel range [cin_off, cin_off + cin_real) (layout 1) or nn.ConvTranspose2d(2, 2) weight [cout][cin / 4][2][2] (layout 2) — no permute-copy, no torch.cat"""
+        need = self.lib.smirk_conv_wgrad_workspace_bytes(B, H, W, cout, cin, k)
+        if self.wg_ws is None or self.wg_ws.numel() < need:
+            self.wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        P = L.ptr
+        cin_total = out.shape[1] if layout == 1 else 0
+        L.check(self.lib.smirk_conv_wgrad_param(P(dz), P(x), P(out), B, H, W, cout, cin, k, int(reflect), layout, cin_total, cin_off,
+                                                cin if cin_real is None else cin_real, int(self.x1), P(self.wg_ws, torch.uint8), self.wg_ws.numel(), self.st))
+        return out
+
     def colsum(self, x):
         C = x.shape[-1]
         out = torch.empty(C, device=self.dev)
@@ -353,23 +365,24 @@ class GeneratorTrainFunction(torch.autograd.Function):
             if dg2 is not None:
                 grads[id(n2.weight)], grads[id(n2.bias)] = dg2, db2
             if need(c2.weight):
-                grads[id(c2.weight)] = _to_conv_weight_grad(ops.wgrad(dz2, y1, B, h, w, c, c, 3), c, c)
+                grads[id(c2.weight)] = ops.wgrad_param(dz2, y1, B, h, w, c, c, 3, torch.empty_like(c2.weight, dtype=torch.float32))
             dy1 = ops.conv(dz2, None, wd2, B, h, w, c)
             dz1, dg1, db1 = ops.bn_backward(z1, dy1, n1, mu1, iv1, True)
             if dg1 is not None:
                 grads[id(n1.weight)], grads[id(n1.bias)] = dg1, db1
             c0 = x0.shape[-1]
             if x1 is None:
-                if need(c1.weight):
-                    grads[id(c1.weight)] = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0, cin_real=c1.weight.shape[1])
+                if need(c1.weight):                                       # (the network input is padded 6 -> 8 channels: the two padded ones are dropped)
+                    grads[id(c1.weight)] = ops.wgrad_param(dz1, x0, B, h, w, c, c0, 3, torch.empty_like(c1.weight, dtype=torch.float32), cin_real=c1.weight.shape[1])
                 if rec is tape[0] and not want_dx:                        # the network input needs no gradient (cycle path: it is detached)
                     return None, None
                 return ops.conv(dz1, None, wd1a, B, h, w, c0), None
             cc1 = x1.shape[-1]
-            if need(c1.weight):
-                gw0 = _to_conv_weight_grad(ops.wgrad(dz1, x0, B, h, w, c, c0, 3), c, c0)
-                gw1 = _to_conv_weight_grad(ops.wgrad(dz1, x1, B, h, w, c, cc1, 3), c, cc1)
-                grads[id(c1.weight)] = torch.cat([gw0, gw1], 1)            # torch.cat((up, skip), 1): channels of source 0 first
+            if need(c1.weight):                                           # torch.cat((up, skip), 1): channels of source 0 first, both into one tensor
+                gw = torch.empty_like(c1.weight, dtype=torch.float32)
+                ops.wgrad_param(dz1, x0, B, h, w, c, c0, 3, gw, cin_off=0)
+                ops.wgrad_param(dz1, x1, B, h, w, c, cc1, 3, gw, cin_off=c0)
+                grads[id(c1.weight)] = gw
             return ops.conv(dz1, None, wd1a, B, h, w, c0), ops.conv(dz1, None, wd1b, B, h, w, cc1)
 
         g = dd
@@ -391,9 +404,8 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 L.check(lib.smirk_space_to_depth2_split16(L.ptr(g), L.ptr(s2d), B, h, w, cout, st))
                 if need(up.bias):
                     grads[id(up.bias)] = ops.colsum(g)
-                if need(up.weight):
-                    gw = ops.wgrad(xin_, s2d, B, h, w, cin, 4 * cout, 1)   # [Cin][(dy,dx,co)]
-                    grads[id(up.weight)] = gw.reshape(cin, 2, 2, cout).permute(0, 3, 1, 2).contiguous()
+                if need(up.weight):                                        # packed [Cin][(dy,dx,co)] -> the parameter's [Cin][Cout][2][2] in the reduction itself
+                    grads[id(up.weight)] = ops.wgrad_param(xin_, s2d, B, h, w, cin, 4 * cout, 1, torch.empty_like(up.weight, dtype=torch.float32), layout=2)
                 wd = _split16(up.weight.detach().float().permute(0, 2, 3, 1).reshape(cin, 4 * cout).contiguous())
                 g = ops.conv(s2d, None, wd, B, h, w, cin, k=1)
             elif kind == "res":
@@ -402,7 +414,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 if dgb is not None:
                     grads[id(nbv.weight)], grads[id(nbv.bias)] = dgb, dbb
                 if need(cbv.weight):
-                    grads[id(cbv.weight)] = _to_conv_weight_grad(ops.wgrad(dzb, ya, B, h, w, c, c, 3, reflect=True), c, c)
+                    grads[id(cbv.weight)] = ops.wgrad_param(dzb, ya, B, h, w, c, c, 3, torch.empty_like(cbv.weight, dtype=torch.float32), reflect=True)
                 dpad = ops.conv(dzb, None, wdb, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 dya = torch.empty_like(ya)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), None, L.ptr(dya), B, h, w, c, st))
@@ -410,7 +422,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 if dga is not None:
                     grads[id(na.weight)], grads[id(na.bias)] = dga, dba
                 if need(ca.weight):
-                    grads[id(ca.weight)] = _to_conv_weight_grad(ops.wgrad(dza, bin_, B, h, w, c, c, 3, reflect=True), c, c)
+                    grads[id(ca.weight)] = ops.wgrad_param(dza, bin_, B, h, w, c, c, 3, torch.empty_like(ca.weight, dtype=torch.float32), reflect=True)
                 dpad = ops.conv(dza, None, wda, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 gin = torch.empty_like(bin_)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), L.ptr(g), L.ptr(gin), B, h, w, c, st))     # + the identity branch

@@ -440,3 +440,41 @@ def test_conv_weight_gradient_f16x1(B, H, W, cin, cout, k, reflect):
     xin = F.pad(x64, (1, 1, 1, 1), mode="reflect") if reflect else x64
     F.conv2d(xin, w, padding=0 if (reflect or k == 1) else 1).backward(d64)
     assert _rel(T._to_conv_weight_grad(dw, cout, cin, k).cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("arith", ["f16x3", "f16x1"])
+def test_weight_gradient_in_parameter_layout_equals_the_packed_one(arith):
+    """smirk_conv_wgrad_param writes the split-K sum straight into nn.Conv2d / nn.ConvTranspose2d parameter layouts (two sources into one tensor, padded input
+    channels dropped): bit-identical to the packed result permuted / concatenated on the host, which is what the backward did through round 4."""
+    from smirk_amd import generator_train as T
+    ops = T._Ops(torch.device("cuda"), arith=arith)
+    g = _gen(123)
+    B, H, W = 2, 16, 16
+    # two-source decoder convolution: cat((up 32 ch, skip 64 ch), 1) -> 64
+    dz, _ = _act(torch.randn(B, H, W, 64, generator=g))
+    x0, _ = _act(torch.randn(B, H, W, 32, generator=g))
+    x1, _ = _act(torch.randn(B, H, W, 64, generator=g))
+    ref = torch.cat([T._to_conv_weight_grad(ops.wgrad(dz, x0, B, H, W, 64, 32, 3), 64, 32), T._to_conv_weight_grad(ops.wgrad(dz, x1, B, H, W, 64, 64, 3), 64, 64)], 1)
+    out = torch.full((64, 96, 3, 3), float("nan"), device="cuda")
+    ops.wgrad_param(dz, x0, B, H, W, 64, 32, 3, out, cin_off=0)
+    ops.wgrad_param(dz, x1, B, H, W, 64, 64, 3, out, cin_off=32)
+    assert torch.equal(out, ref)
+    # first layer: 6 real of 8 padded input channels
+    x8, _ = _act(torch.randn(B, H, W, 8, generator=g))
+    d32, _ = _act(torch.randn(B, H, W, 32, generator=g))
+    ref = T._to_conv_weight_grad(ops.wgrad(d32, x8, B, H, W, 32, 8, 3), 32, 8, cin_real=6)
+    out = torch.full((32, 6, 3, 3), float("nan"), device="cuda")
+    ops.wgrad_param(d32, x8, B, H, W, 32, 8, 3, out, cin_real=6)
+    assert torch.equal(out, ref)
+    # reflect-padded ResNet convolution
+    a, _ = _act(torch.randn(B, 6, 6, 64, generator=g)); b_, _ = _act(torch.randn(B, 6, 6, 64, generator=g))
+    ref = T._to_conv_weight_grad(ops.wgrad(a, b_, B, 6, 6, 64, 64, 3, reflect=True), 64, 64)
+    out = torch.full((64, 64, 3, 3), float("nan"), device="cuda")
+    ops.wgrad_param(a, b_, B, 6, 6, 64, 64, 3, out, reflect=True)
+    assert torch.equal(out, ref)
+    # ConvTranspose2d(64, 32, 2, 2): dz = the layer's input (64 ch), x = space-to-depth of the output gradient (4 x 32 ch)
+    xin, _ = _act(torch.randn(B, H, W, 64, generator=g)); s2d, _ = _act(torch.randn(B, H, W, 128, generator=g))
+    ref = ops.wgrad(xin, s2d, B, H, W, 64, 128, 1).reshape(64, 2, 2, 32).permute(0, 3, 1, 2).contiguous()
+    out = torch.full((64, 32, 2, 2), float("nan"), device="cuda")
+    ops.wgrad_param(xin, s2d, B, H, W, 64, 128, 1, out, layout=2)
+    assert torch.equal(out, ref)
