@@ -248,16 +248,23 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         const int q = ((nv + 3) / 4 + 63) & ~63, lo = wave * q, hi = min(lo + q, nv);
         unsigned short* mylist = slist + wave * qmax;
         int c = 0;
-        for (int base = lo; base < hi; base += 64) {
-            const int s = base + lane;
-            bool hit = false;
-            if (s < hi) {
-                const short4 bx = boxes[s];
-                hit = bx.x <= tx1 && bx.y >= tx0 && bx.z <= ty1 && bx.w >= ty0 && bx.x <= bx.y;
+        // eight 64-face rounds of boxes are requested before the first is tested: one global round trip per eight rounds instead of one per round (the ballot of a
+        // round needs its boxes, so a rolled loop paid ~14 dependent L2 / HBM latencies per wave — most of a tile's time once the depth culling had removed the face loop)
+        for (int base = lo; base < hi; base += 64 * 8) {
+            short4 bx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = base + 64 * u + lane;
+                bx[u] = boxes[min(s, nv - 1)];
             }
-            const unsigned long long mk = __ballot(hit);
-            if (hit) mylist[c + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)s;
-            c += __popcll(mk);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = base + 64 * u + lane;
+                const bool hit = s < hi && bx[u].x <= tx1 && bx[u].y >= tx0 && bx[u].z <= ty1 && bx[u].w >= ty0 && bx[u].x <= bx[u].y;
+                const unsigned long long mk = __ballot(hit);
+                if (hit) mylist[c + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)s;
+                c += __popcll(mk);
+            }
         }
         if (lane == 0) scnt[wave] = c;
     }
