@@ -379,6 +379,7 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
     if (ws_bytes < p.total) return SMIRK_ERR_WORKSPACE;
     const bool split = w->precision == SMIRK_PRECISION_F16X3;
     const bool no_image = getenv("SMIRK_DISABLE_MBCONV_IMAGE") != nullptr;                                                       // A/B switch (tests)
+    const bool no_tile = getenv("SMIRK_DISABLE_MBCONV_TILE") != nullptr;      // A/B switch (tests): the 24-48-channel blocks stay on mbconv_fused_kernel
     const bool no_fuse = getenv("SMIRK_DISABLE_MBCONV_FUSED") != nullptr;                                                         // A/B switch (tests)
     const bool fuse_ds = false;       // DepthwiseSeparable blocks stay unfused (no expanded tensor to save: 202 vs 200 us at stride 1, 97 vs 66 at stride 2)
     int h = (H + 1) / 2, wd = (W + 1) / 2;
@@ -414,6 +415,13 @@ extern "C" int smirk_backbone_forward(const SmirkBackboneWeights* w, const float
         if (b.kind == 2) {                                          // ConvBnAct 1x1
             void* o = p.rot.pick(x, nullptr);
             TRY(pointwise(x, h, wd, b.cin, b.cout, b.pw, true, nullptr, o));
+            x = o;
+        } else if (split && !no_fuse && !no_image && !no_tile && b.kind == 1 && b.cin <= 48 && smirk_mbconv_image_supported(h, wd, b.cin, b.mid, b.cout, b.stride)) {
+            // stride-1 blocks of the 56 x 56 / 28 x 28 stages (14 x 14 halo tiles) and of the small backbone's 14 x 14 stage (whole images), 24-48 channels:
+            // the image-resident kernel instead of the 8 x 8-tile kernel below (round 5)
+            void* o = p.rot.pick(x, nullptr);
+            TRY(smirk_mbconv_image_split16(x, b.pw.w, b.pw.scale, b.pw.shift, (const float*)b.dw.w, b.dw.scale, b.dw.shift, b.pwl.w, b.pwl.scale, b.pwl.shift,
+                                           b.skip ? 1 : 0, o, B, h, wd, b.cin, b.mid, b.cout, stream));
             x = o;
         } else if (split && !no_fuse && (b.kind == 1 || fuse_ds) && smirk_mbconv_supported(b.cin, b.mid, b.cout, b.stride)) {
             void* o = p.rot.pick(x, nullptr);

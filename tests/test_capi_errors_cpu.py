@@ -93,8 +93,11 @@ def test_fused_encoder_entries_round3(lib):
     ms = lib.smirk_mbconv_image_supported
     for H, Cin, mid, Cout in ((14, 80, 200, 80), (14, 80, 184, 80), (14, 80, 480, 112), (14, 112, 672, 112),       # large, 14 x 14
                               (14, 40, 240, 40), (14, 40, 120, 48), (14, 48, 144, 48), (7, 96, 576, 96)):           # small, 14 x 14 and 7 x 7
-        expect = 1 if Cin >= 64 else 0                                                    # KS = Cin / 16 variants 4..7 only: the 40/48-channel blocks stay on mbconv_fused
-        assert ms(H, H, Cin, mid, Cout, 1) == expect, (H, Cin, mid, Cout)
+        assert ms(H, H, Cin, mid, Cout, 1) == 1, (H, Cin, mid, Cout)                     # (round 5: the 40 / 48-channel blocks too, K padded to a multiple of 16)
+    for H, Cin, mid, Cout in ((56, 24, 72, 24), (28, 40, 120, 40), (28, 24, 88, 24), (112, 24, 72, 24)):           # round 5: 14 x 14 halo tiles of larger images
+        assert ms(H, H, Cin, mid, Cout, 1) == 1, (H, Cin, mid, Cout)
+    assert ms(30, 30, 40, 120, 40, 1) == 0 and ms(28, 30, 40, 120, 40, 1) == 0            # ... whose sides are multiples of 14
+    assert ms(28, 28, 40, 120, 40, 2) == 0
     assert ms(14, 14, 80, 200, 80, 2) == 0                                                # stride-2 blocks are not whole-image blocks
     assert ms(28, 28, 80, 200, 80, 1) == 0                                                # an image must fit the 224-row workgroup
     assert ms(7, 7, 160, 960, 160, 1) == 0                                                # the 160-channel stage is not instantiated

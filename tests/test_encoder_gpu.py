@@ -191,7 +191,12 @@ def test_fused_encoder_head_matches_three_launch_sequence(enc, hw):
 @pytest.mark.parametrize("cfg", [dict(B=3, H=14, W=14, cin=112, mid=672, cout=112, res=True), dict(B=5, H=7, W=7, cin=96, mid=576, cout=96, res=True),
                                  dict(B=2, H=14, W=14, cin=80, mid=200, cout=80, res=True), dict(B=4, H=14, W=14, cin=80, mid=184, cout=80, res=True),
                                  dict(B=3, H=14, W=14, cin=80, mid=480, cout=112, res=False), dict(B=9, H=5, W=7, cin=64, mid=136, cout=48, res=False),
-                                 dict(B=2, H=13, W=12, cin=112, mid=96, cout=88, res=False)])
+                                 dict(B=2, H=13, W=12, cin=112, mid=96, cout=88, res=False),
+                                 # round 5: K padded to a multiple of 16 (24 / 40 channels) and 14 x 14 halo tiles of 28 x 28 / 56 x 56 / 28 x 42 images
+                                 dict(B=3, H=14, W=14, cin=40, mid=240, cout=40, res=True), dict(B=2, H=14, W=14, cin=40, mid=120, cout=48, res=False),
+                                 dict(B=2, H=14, W=14, cin=48, mid=144, cout=48, res=True), dict(B=3, H=28, W=28, cin=40, mid=120, cout=40, res=True),
+                                 dict(B=2, H=56, W=56, cin=24, mid=72, cout=24, res=True), dict(B=2, H=28, W=28, cin=24, mid=88, cout=24, res=True),
+                                 dict(B=1, H=28, W=42, cin=40, mid=120, cout=40, res=False)])
 def test_mbconv_image_kernel_vs_float64(cfg):
     """csrc/mbconv_image.hip: 1x1 expand + BN + ReLU -> 3x3 depthwise (pad 1) + BN + ReLU -> 1x1 project + BN (+ x), whole images per workgroup, against
     torch float64 on the operands' exact split16 values: the backbones' 14x14 / 7x7 shapes (ragged last chunk: mid 200 / 184; ragged last workgroup:
@@ -227,6 +232,26 @@ def test_mbconv_image_kernel_vs_float64(cfg):
     got = split16_to_float(out).permute(0, 3, 1, 2).cpu().double()
     # D is rounded to the 22-bit split16 fragment format before the project GEMM (as in mbconv.hip and the unfused sequence): 2^-22 relative per term
     assert (got - ref).abs().max().item() < 4e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (448, 224)])
+def test_halo_tiled_mbconv_blocks_match_the_8x8_tile_kernel_and_the_unfused_sequence(enc, hw):
+    """round 5: the 24-48-channel stride-1 blocks on 14 x 14 halo tiles (mbconv_image_kernel<2,1,true,true> / <3,2,true,true>) against the kernel they replace
+    ($SMIRK_DISABLE_MBCONV_TILE) and against the pointwise / depthwise / pointwise launches ($SMIRK_DISABLE_MBCONV_FUSED); 448 x 224: 8 x 4 and 4 x 2 tiles"""
+    from smirk_amd.smirk_encoder import features_f32
+    m, _ = enc
+    img = torch.cat([A.synth_images(2, seed=37), A.synth_images(2, seed=38)], 2)[:, :, :hw[0], :hw[1]].contiguous().cuda()
+    for name in ("pose_encoder", "shape_encoder"):
+        bb = getattr(m, name).encoder
+        got = features_f32(bb, bb(img)).cpu()
+        for env in ("SMIRK_DISABLE_MBCONV_TILE", "SMIRK_DISABLE_MBCONV_FUSED"):
+            os.environ[env] = "1"
+            try:
+                ref = features_f32(bb, bb(img)).cpu()
+            finally:
+                del os.environ[env]
+            assert got.shape == ref.shape
+            assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), (name, env)
 
 
 @pytest.mark.parametrize("hw,B", [((224, 224), 3), ((224, 224), 5), ((200, 184), 2), ((72, 104), 9)])
