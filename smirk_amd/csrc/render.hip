@@ -284,6 +284,14 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
     const float sx_hi = pix_to_ndc(W - 1 - wx0, W), sx_lo = pix_to_ndc(W - 1 - (wx0 + 7), W);
     const float sy_hi = pix_to_ndc(H - 1 - ty0, H), sy_lo = pix_to_ndc(H - 1 - (ty0 + TILE_H - 1), H);
     const float INF = __uint_as_float(0x7f800000u);
+    // the records of a chunk are requested one chunk ahead (by the 64 threads that stage them) and land under the previous chunk's face loop: the LDS list lookup ->
+    // global load -> LDS store chain was ~2 us per chunk in front of a face loop that the depth culling had made short
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+    auto fetch_record = [&](int i) {
+        const int s = i < n0 ? slist[i] : i < n1 ? slist[qmax + i - n0] : i < n2 ? slist[2 * qmax + i - n1] : slist[3 * qmax + i - n2];
+        g0 = *(const float4*)(fr + (size_t)s * FREC_G); g1 = *(const float4*)(fr + (size_t)s * FREC_G + 4); g2 = *(const float4*)(fr + (size_t)s * FREC_G + 8);
+    };
+    if (tid < min(FACE_CHUNK, n)) fetch_record(tid);
     for (int base = 0; base < n; base += FACE_CHUNK) {
         const int cnt = min(FACE_CHUNK, n - base);
         // depth the block's pixels hold now: +inf while any of them is uncovered (pixels outside the image do not count).  It only falls as faces are
@@ -295,10 +303,6 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         // -ffp-contract=off) the per-pixel code used, so every value is bit-identical: vertices, area + eps, the face's NDC box and the
         // (b - a) factors of the three edge functions
         if (tid < cnt) {
-            const int i = base + tid;
-            const int s = i < n0 ? slist[i] : i < n1 ? slist[qmax + i - n0] : i < n2 ? slist[2 * qmax + i - n1] : slist[3 * qmax + i - n2];
-            const float4 g0 = *(const float4*)(fr + (size_t)s * FREC_G), g1 = *(const float4*)(fr + (size_t)s * FREC_G + 4),
-                         g2 = *(const float4*)(fr + (size_t)s * FREC_G + 8);
             const float x0 = g0.x, y0 = g0.y, z0 = g0.z, x1 = g0.w, y1 = g1.x, z1 = g1.y, x2 = g1.z, y2 = g1.w, z2 = g2.x;
             float* r = sface + tid * FACE_REC;
             r[0] = x0; r[1] = y0; r[2] = z0; r[3] = x1; r[4] = y1; r[5] = z1; r[6] = x2; r[7] = y2; r[8] = z2;
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         __syncthreads();
         // every face from here on has zlow >= this chunk's first (ascending order): once all four blocks are covered in front of it the tile is done
         if (fmaxf(fmaxf(szmx[0], szmx[1]), fmaxf(szmx[2], szmx[3])) < sface[20]) break;
+        if (base + FACE_CHUNK + tid < n && tid < FACE_CHUNK) fetch_record(base + FACE_CHUNK + tid);       // the next chunk's records
         // wave-level cull: a wave owns an 8 x 8 pixel block; lane l tests face l of the chunk against the block's NDC box (64 faces in parallel,
         // one LDS read each) and only the faces that can touch the strip are walked.  Conservative w.r.t. the per-pixel box test below (a face
         // whose box misses the strip fails that test at every pixel of it), so the result is unchanged; it removes the serial
