@@ -354,9 +354,14 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
             // the whole record in six 16-byte broadcast reads, then straight-line arithmetic: the box test no longer costs four dependent LDS round trips
             const float4* v4 = (const float4*)(sface + j * FACE_REC);
             const float4 c0 = v4[0], c1 = v4[1], c2 = v4[2], c3 = v4[3], c4 = v4[4];
+            const float zl = sface[j * FACE_REC + 20];
             const float x0 = c0.x, y0 = c0.y, x1 = c0.w, y1 = c1.x, x2 = c1.z, y2 = c1.w;
             const float area = c2.y;
-            const bool inbox = !(xf > c2.w || xf < c2.z || yf > c3.y || yf < c3.x);
+            // a pixel of the face's box that already holds a depth strictly below the face's lower depth bound cannot be won by this face: it is not a candidate.
+            // A block at the silhouette is never covered as a whole (no block-level cull), but the ~24 layers behind its covered part have no candidate pixel
+            // left and are dropped here, before the edge functions and the divisions.
+            const bool inbox = !(xf > c2.w || xf < c2.z || yf > c3.y || yf < c3.x) && !(best_f >= 0 && best_z < zl);
+            if (__ballot(inbox) == 0ull) continue;
             const float e0 = (xf - x1) * c3.z - (yf - y1) * c3.w;
             const float e1 = (xf - x2) * c4.x - (yf - y2) * c4.y;
             const float e2 = (xf - x0) * c4.z - (yf - y0) * c4.w;
