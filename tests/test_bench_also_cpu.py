@@ -1,0 +1,35 @@
+"""bench.py's "also" block (the other BASELINE configs as child processes): the bookkeeping around the children, exercised without a GPU.  Here every
+child exits with "bench.py needs an MI355X", which is exactly the path that must not take the headline line down: each entry reports its error and wall time."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_also_specs_name_every_baseline_config_and_failures_are_contained():
+    sys.path.insert(0, REPO)
+    import bench
+    names = [s[0] for s in bench.ALSO_SPECS]
+    assert names == ["flame512", "infer256", "train64_f16x3", "train64_f16x1", "full_shard128_collective"]
+    wl = {s[0]: s[1] for s in bench.ALSO_SPECS}
+    assert wl["full_shard128_collective"] == ["--workload", "full", "--global-batch", "128", "--force-collective"]
+    assert wl["train64_f16x1"][-1] == "f16x1" and wl["train64_f16x3"][-1] == "f16x3"
+    import torch
+    if torch.cuda.is_available():
+        return                                                         # on a GPU box the children really run: covered by the bench line itself
+    args = bench.parse_args([])
+    out = bench.run_also(args)
+    assert set(names) <= set(out) and "_note" in out
+    for n in names:
+        assert "error" in out[n] and "MI355X" in out[n]["error"] and out[n]["wall_s"] >= 0, out[n]
+
+
+def test_child_command_line_is_one_a_builder_can_run_by_hand():
+    """every child argv parses with bench.py's own parser and switches off what only the parent does (also, counter passes, CPU baseline)"""
+    sys.path.insert(0, REPO)
+    import bench
+    for name, argv, steps, warmup in bench.ALSO_SPECS:
+        a = bench.parse_args(argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", "0", "--no-also"])
+        assert a.no_also and a.traffic == "off" and a.cpu_faces == 0 and a.steps == steps and a.gpus == 1, name
