@@ -67,6 +67,34 @@ def test_render_matches_oracle_bit_exact_indices(rend, sandbox, B, seed):
     assert 0.1 < cov < 0.9
 
 
+@pytest.mark.parametrize("kind", ["cloud", "flat", "layers", "slivers"])
+def test_render_depth_culling_is_bit_exact_on_adversarial_vertex_sets(rend, sandbox, kind):
+    """round 5: the rasteriser sorts faces front to back and culls by a per-face lower depth bound (csrc/render.hip).  The FLAME-shaped meshes of the
+    other tests are kind to that; these vertex sets are not: a random point cloud (every triangle spans the image, hundreds of layers, wild depth ranges), an exactly
+    FLAT mesh (every face at the same depth: every comparison is a tie on pz, the lower face index must win), two coincident layers a hair apart, and near-degenerate
+    slivers (the bound must give up: rho large).  pix_to_face / barycentrics / z-buffer must equal the naive oracle bit for bit."""
+    rng = np.random.default_rng({"cloud": 1, "flat": 2, "layers": 3, "slivers": 4}[kind])
+    B, V = 3, 5023
+    base = FlameRef(sandbox).forward(A.synth_flame_params(B, seed=17))["vertices"]
+    if kind == "cloud":
+        verts = rng.uniform(-0.12, 0.12, (B, V, 3)).astype(np.float32)
+    elif kind == "flat":
+        verts = base.copy(); verts[..., 2] = 0.0                                 # orthographic projection: xy untouched, all depths equal
+    elif kind == "layers":
+        verts = base.copy(); verts[:, ::2, 2] = 0.01; verts[:, 1::2, 2] = 0.01 + 1e-6
+    else:
+        verts = base.copy(); verts[..., 1] = verts[..., 0] * 0.5 + rng.normal(0, 2e-6, (B, V)).astype(np.float32)   # all vertices almost on one line
+    cam = np.array([[8, 0.0, 0.0], [6, 0.02, -0.03], [10, -0.05, 0.04]], np.float32)
+    ref = RendererRef(sandbox).forward(verts, cam)
+    out, aux = _gpu(rend, verts, cam)
+    p2f = ref["_aux"]["pix_to_face"].astype(np.int64)
+    packed = np.where(p2f >= 0, p2f + (np.arange(B, dtype=np.int64) * 3408)[:, None, None], -1)
+    assert np.array_equal(aux["pix_to_face"], packed), kind
+    assert np.array_equal(aux["bary"], ref["_aux"]["bary"]) and np.array_equal(aux["zbuf"], ref["_aux"]["zbuf"]), kind
+    if kind != "slivers":
+        assert (packed >= 0).mean() > 0.05, kind                                # the case really draws something
+
+
 def test_render_edge_cases(rend, sandbox):
     """mesh partly / wholly off-screen, tiny scale (sub-pixel triangles), huge scale (few big triangles)."""
     fr = FlameRef(sandbox)
