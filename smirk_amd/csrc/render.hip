@@ -324,9 +324,13 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
         // whose box misses the strip fails that test at every pixel of it), so the result is unchanged; it removes the serial
         // read-compare-branch per face and pixel that made this loop 90 % of the kernel (tools/raster_time.py).
         bool rel = false;
-        if (lane < cnt) {
+        float zc = 0.f;                                           // this lane's face: lower bound of its depth INSIDE THIS BLOCK (>= the face's zlow)
+        // a block that is already covered in front of this chunk's first (= nearest) face is finished for good — its wave only keeps the barriers company while
+        // the tile's other blocks go on (the tile-level exit above needs all four)
+        if (lane < cnt && !(zblock < sface[20])) {
             const float* r = sface + lane * FACE_REC;
             rel = !(sx_lo > r[11] || sx_hi < r[10] || sy_lo > r[13] || sy_hi < r[12]) && !(r[20] > zblock);      // depth: see face_zlow
+            zc = r[20];
             // Edge test of the whole block (the synthetic FLAME basis stretches triangles to ~21 x 22-pixel boxes: a box overlaps many blocks its
             // triangle never enters).  A pixel is covered only if s e_k > 0 for all three edge functions, s = sign(area + eps); e_k is linear in the
             // pixel centre, so its maximum over the block sits at a corner and separates into an x and a y term.  The face is dropped when that
@@ -345,6 +349,32 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
                     const float mag = fabsf(A) * fmaxf(fabsf(dx0), fabsf(dx1)) + fabsf(Bc) * fmaxf(fabsf(dy0), fabsf(dy1));
                     if (emax < -1e-5f * mag) rel = false;
                 }
+                // Depth of the face's PLANE over this block.  The interpolated depth is the affine function F(p) = sum_k z_k e_k(p) / A of the pixel centre; over the
+                // block's centres (within +-3.5 pixels of its middle m) F(p) >= F(m) - |dF/dx| hx - |dF/dy| hy.  The per-pixel code computes pz >= F(p) - zmax (24u ext^2 /
+                // |A| + 6u) for a covered pixel (face_zlow's derivation), and F(m), dF/dx, dF/dy computed here in fp32 are within zmax 39u D^2 / |A| of their exact values
+                // (D = face extent + block extent: the middle may lie outside the face's box).  err below is 3x their sum; the bound is dropped for ill-conditioned
+                // faces (rho2 not small).  A face whose nearest VERTEX is in front of the surface but whose plane passes behind it in this block is culled by this
+                // bound and not by zlow (tests/test_raster_zbound_cpu.py checks both against the per-pixel arithmetic).
+                if (rel) {
+                    const float z0 = r[2], z1 = r[5], z2 = r[8];
+                    const float zmx = fmaxf(z0, fmaxf(z1, z2)), zmn = fminf(z0, fminf(z1, z2));
+                    const float D = ((r[11] - r[10]) + (r[13] - r[12])) + ((sx_hi - sx_lo) + (sy_hi - sy_lo));
+                    const float rho2 = (1e-8f + 1.2e-5f * D * D) / fabsf(area);                  // 200 u = 1.2e-5
+                    if (rho2 < 0.01f && zmn > 1e-3f) {
+                        const float inva = 1.0f / area;
+                        const float cxm = 0.5f * (sx_lo + sx_hi), cym = 0.5f * (sy_lo + sy_hi);
+                        const float hx = 0.5f * (sx_hi - sx_lo) * 1.00001f, hy = 0.5f * (sy_hi - sy_lo) * 1.00001f;
+                        const float e0m = (cxm - r[3]) * r[14] - (cym - r[4]) * r[15];
+                        const float e1m = (cxm - r[6]) * r[16] - (cym - r[7]) * r[17];
+                        const float e2m = (cxm - r[0]) * r[18] - (cym - r[1]) * r[19];
+                        const float Fm = ((e0m * z0 + e1m * z1) + e2m * z2) * inva;
+                        const float gx = ((z0 * r[14] + z1 * r[16]) + z2 * r[18]) * inva, gy = ((z0 * r[15] + z1 * r[17]) + z2 * r[19]) * inva;
+                        const float var = fabsf(gx) * hx + fabsf(gy) * hy;
+                        const float zb = ((Fm - var) - (zmx * rho2 + (fabsf(Fm) + var) * 1e-5f)) * (1.0f - 2e-6f);
+                        zc = fmaxf(zc, zb);                       // (NaN -> zc)
+                        if (zc > zblock) rel = false;
+                    }
+                }
             }
         }
         unsigned long long relmask = __ballot(rel);
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(256) void raster_tile(MeshDev m, int B, int H, int 
             // the whole record in six 16-byte broadcast reads, then straight-line arithmetic: the box test no longer costs four dependent LDS round trips
             const float4* v4 = (const float4*)(sface + j * FACE_REC);
             const float4 c0 = v4[0], c1 = v4[1], c2 = v4[2], c3 = v4[3], c4 = v4[4];
-            const float zl = sface[j * FACE_REC + 20];
+            const float zl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zc), j));    // lane j's bound for ITS face in this block
             const float x0 = c0.x, y0 = c0.y, x1 = c0.w, y1 = c1.x, x2 = c1.z, y2 = c1.w;
             const float area = c2.y;
             // a pixel of the face's box that already holds a depth strictly below the face's lower depth bound cannot be won by this face: it is not a candidate.

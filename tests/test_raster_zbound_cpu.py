@@ -26,6 +26,31 @@ def face_zlow(p):
     return np.where((rho < f32(0.25)) & (zmin > f32(1e-3)), z, f32(0.0)).astype(f32), A
 
 
+def block_zc(p, A, zlow, sx_lo, sx_hi, sy_lo, sy_hi):
+    """numpy float32 restatement of the per-(face, block) plane bound of raster_tile's cull stage, same operation order; scalars for one face and one block"""
+    x0, y0, z0, x1, y1, z1, x2, y2, z2 = (f32(v) for v in p)
+    zmx, zmn = max(z0, z1, z2), min(z0, z1, z2)
+    ext = f32(f32(max(x0, x1, x2) - min(x0, x1, x2)) + f32(max(y0, y1, y2) - min(y0, y1, y2)))
+    D = f32(ext + f32(f32(sx_hi - sx_lo) + f32(sy_hi - sy_lo)))
+    with np.errstate(all="ignore"):
+        rho2 = f32(f32(f32(1e-8) + f32(f32(f32(1.2e-5) * D) * D)) / abs(A))
+    if not (rho2 < f32(0.01) and zmn > f32(1e-3)):
+        return zlow
+    r14, r15, r16, r17, r18, r19 = f32(y2 - y1), f32(x2 - x1), f32(y0 - y2), f32(x0 - x2), f32(y1 - y0), f32(x1 - x0)
+    inva = f32(f32(1.0) / A)
+    cxm, cym = f32(f32(0.5) * f32(sx_lo + sx_hi)), f32(f32(0.5) * f32(sy_lo + sy_hi))
+    hx, hy = f32(f32(f32(0.5) * f32(sx_hi - sx_lo)) * f32(1.00001)), f32(f32(f32(0.5) * f32(sy_hi - sy_lo)) * f32(1.00001))
+    e0m = f32(f32(f32(cxm - x1) * r14) - f32(f32(cym - y1) * r15))
+    e1m = f32(f32(f32(cxm - x2) * r16) - f32(f32(cym - y2) * r17))
+    e2m = f32(f32(f32(cxm - x0) * r18) - f32(f32(cym - y0) * r19))
+    Fm = f32(f32(f32(f32(e0m * z0) + f32(e1m * z1)) + f32(e2m * z2)) * inva)
+    gx = f32(f32(f32(f32(z0 * r14) + f32(z1 * r16)) + f32(z2 * r18)) * inva)
+    gy = f32(f32(f32(f32(z0 * r15) + f32(z1 * r17)) + f32(z2 * r19)) * inva)
+    var = f32(f32(abs(gx) * hx) + f32(abs(gy) * hy))
+    zb = f32(f32(f32(Fm - var) - f32(f32(zmx * rho2) + f32(f32(abs(Fm) + var) * f32(1e-5)))) * f32(1.0 - 2e-6))
+    return zlow if not (zb > zlow) else zb
+
+
 def _triangles(rng, n):
     """a mix of shapes in the NDC square, z around SMIRK's +10 offset and down to the validity cut-off"""
     kind = rng.integers(0, 6, n)
@@ -84,3 +109,49 @@ def test_zlow_gives_up_on_degenerate_faces():
                   [0, 0, np.nan, 0.2, 0, 10, 0, 0.2, 10]], f32)
     z, _ = face_zlow(p)
     assert z[0] == 0 and 9.99 < z[1] < 10 and z[2] == 0 and z[3] == 0
+
+
+def test_block_plane_bound_is_a_lower_bound_inside_the_block():
+    """the per-(face, 8 x 8 block) bound of the cull stage (plane depth at the block's middle minus its variation over the block minus the error terms) against the
+    per-pixel arithmetic, for every 8 x 8 block a triangle's box touches; it must also be USEFUL: for slanted triangles it beats the nearest-vertex bound"""
+    rng = np.random.default_rng(11)
+    H = W = 224
+    p = _triangles(rng, 6000)
+    zlow, A = face_zlow(p)
+    ndc = (f32(-1.0) + (f32(2.0) * np.arange(W, dtype=f32)[::-1] + f32(1.0)).astype(f32) / f32(W)).astype(f32)      # pixel index i -> NDC
+    checked = tighter = blocks = 0
+    for k in range(p.shape[0]):
+        if A[k] == 0:
+            continue
+        x0, y0, z0, x1, y1, z1, x2, y2, z2 = (p[k:k + 1, j] for j in range(9))
+        xmin, xmax = min(x0[0], x1[0], x2[0]), max(x0[0], x1[0], x2[0])
+        ymin, ymax = min(y0[0], y1[0], y2[0]), max(y0[0], y1[0], y2[0])
+        xi = np.nonzero((ndc >= xmin) & (ndc <= xmax))[0]
+        yi = np.nonzero((ndc >= ymin) & (ndc <= ymax))[0]
+        if xi.size == 0 or yi.size == 0:
+            continue
+        bxs, bys = np.unique(xi // 8), np.unique(yi // 8)
+        if bxs.size * bys.size > 12:                                  # huge triangles: a random subset of their blocks
+            bxs, bys = rng.choice(bxs, min(bxs.size, 4), replace=False), rng.choice(bys, min(bys.size, 3), replace=False)
+        for bx in bxs:
+            for by in bys:
+                px, py = np.meshgrid(ndc[bx * 8:bx * 8 + 8], ndc[by * 8:by * 8 + 8])
+                px, py = px.ravel(), py.ravel()
+                inb = (px >= xmin) & (px <= xmax) & (py >= ymin) & (py <= ymax)
+                if not inb.any():
+                    continue
+                with np.errstate(all="ignore"):
+                    w0 = (_E(px, py, x1, y1, x2, y2) / A[k]).astype(f32)
+                    w1 = (_E(px, py, x2, y2, x0, y0) / A[k]).astype(f32)
+                    w2 = (_E(px, py, x0, y0, x1, y1) / A[k]).astype(f32)
+                    pz = (((w0 * z0).astype(f32) + (w1 * z1).astype(f32)).astype(f32) + (w2 * z2).astype(f32)).astype(f32)
+                ok = inb & (w0 > 0) & (w1 > 0) & (w2 > 0) & ~(pz < 0)
+                blocks += 1
+                # block NDC box exactly as the kernel forms it: pix_to_ndc of the block's first / last pixel index (NDC decreases with the index)
+                zc = block_zc(p[k], A[k], zlow[k], ndc[bx * 8 + 7], ndc[bx * 8], ndc[by * 8 + 7], ndc[by * 8])
+                if ok.any():
+                    checked += int(ok.sum())
+                    assert pz[ok].min() >= zc, (k, bx, by, p[k], float(pz[ok].min()), float(zc), float(zlow[k]))
+                tighter += int(zc > zlow[k] * f32(1.0005))
+    assert checked > 100000 and blocks > 20000, (checked, blocks)
+    assert tighter > blocks // 4, (tighter, blocks)
