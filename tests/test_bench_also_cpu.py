@@ -33,3 +33,33 @@ def test_child_command_line_is_one_a_builder_can_run_by_hand():
     for name, argv, steps, warmup in bench.ALSO_SPECS:
         a = bench.parse_args(argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", "0", "--no-also"])
         assert a.no_also and a.traffic == "off" and a.cpu_faces == 0 and a.steps == steps and a.gpus == 1, name
+
+
+def test_rocprofv3_per_launch_figure_is_quoted_only_for_the_same_kernel_sources(tmp_path, monkeypatch):
+    """roofline.rocprofv3: bench.py quotes rocprofv3's own per-launch average of its dominant kernel from profiles/rocprofv3_kernel_avg_<workload>.json — and withholds it
+    (with the reason) when that summary was taken on other kernel sources, for another kernel, or does not exist"""
+    sys.path.insert(0, REPO)
+    import bench
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "kernel_sources_sha", lambda: "abc")
+    r = bench.rocprofv3_avg("full", "conv_halo_kernel<5,0>[256x128,8w,halo]")
+    assert r["avg_launch_us"] is None and "no profiles/" in r["why"]
+    f = tmp_path / "profiles" / "rocprofv3_kernel_avg_full.json"
+    f.write_text(json.dumps({"kernel_sources_sha": "OTHER", "command": "c", "summary_file": "s.txt", "kernels": {"conv_halo_kernel<5,0>": {"calls": 96, "avg_us": 2600.0}}}))
+    r = bench.rocprofv3_avg("full", "conv_halo_kernel<5,0>[256x128,8w,halo]")
+    assert r["avg_launch_us"] is None and "other kernel sources" in r["why"]
+    f.write_text(json.dumps({"kernel_sources_sha": "abc", "command": "c", "summary_file": "s.txt", "kernels": {"conv_halo_kernel<5,0>": {"calls": 96, "avg_us": 2600.0}}}))
+    r = bench.rocprofv3_avg("full", "conv_halo_kernel<5,0>[256x128,8w,halo]")
+    assert r["avg_launch_us"] == 2600.0 and r["calls"] == 96 and r["file"] == "profiles/s.txt"
+    assert bench.rocprofv3_avg("full", "raster_tile")["avg_launch_us"] is None
+
+
+def test_committed_evidence_belongs_to_the_committed_kernel_sources():
+    """the PMC traffic table and the rocprofv3 per-launch averages under profiles/ that bench.py reads were taken on the kernel sources in the tree"""
+    sys.path.insert(0, REPO)
+    import bench
+    sha = bench.kernel_sources_sha()
+    for name in ("pmc_traffic_full.json", "rocprofv3_kernel_avg_full.json", "rocprofv3_kernel_avg_train64.json"):
+        j = json.load(open(os.path.join(REPO, "profiles", name)))
+        assert j["kernel_sources_sha"] == sha, name
