@@ -714,7 +714,7 @@ def run_also(args):
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", "0", "--no-also",
                                                                     "--flame-basis", args.flame_basis]
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, cwd=REPO)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=REPO)
             lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 raise RuntimeError(f"rc={r.returncode}: {r.stderr.decode(errors='replace')[-300:]}")
