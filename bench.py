@@ -93,6 +93,7 @@ def parse_args(argv=None):
     ap.add_argument("--given-masked", action="store_true",
                     help="feed a precomputed masked image instead of running the masking utilities (mesh sampling + masking) in the step")
     ap.add_argument("--cpu-faces", type=int, default=24, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median reported; the `also` children use 3)")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU baseline with os.cpu_count() threads (takes ~15 min on a 256-thread host: the sample is too small for that many threads)")
     ap.add_argument("--traffic", choices=("measure", "file", "off"), default=None,
@@ -183,19 +184,19 @@ def output_stats(out):
 # ------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle = a port of the reference path; checker code, timed beside the GPU on a bounded sample)
 # ------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sandbox, workload, n_faces, threads=None, all_cores=False):
+def cpu_baseline(sandbox, workload, n_faces, threads=None, all_cores=False, passes=5):
     """threads=None: the 32-thread measurement.  all_cores=True (--cpu-all-cores) adds, under "all_cores", the same sample with
     torch.set_num_threads(os.cpu_count()) as BASELINE.md section 3 asks - opt-in, because on the 256-thread GPU host that leg oversubscribes
     the torch-CPU convolutions of a 24-frame sample so badly (0.19 faces/s against 7.8 at 32 threads: profiles/r03z_bench_full.json) that it
     alone takes 15 minutes.  threads=N: that thread count only."""
     if threads is None:
-        base = cpu_baseline(sandbox, workload, n_faces, threads=min(os.cpu_count(), 32))
+        base = cpu_baseline(sandbox, workload, n_faces, threads=min(os.cpu_count(), 32), passes=passes)
         if all_cores and os.cpu_count() > base["cores"]:
-            allc = cpu_baseline(sandbox, workload, n_faces, threads=os.cpu_count())
+            allc = cpu_baseline(sandbox, workload, n_faces, threads=os.cpu_count(), passes=passes)
             base["all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "stage_seconds", "sample")}
         elif os.cpu_count() > base["cores"]:
-            base["all_cores"] = ("not run by default (opt in with --cpu-all-cores); measured on the 256-thread MI355X host in round 3: 0.19 faces/s (full), "
-                                 "0.24 faces/s (infer256) at 256 threads against 7.8 / 11.8 at 32 - profiles/r03z_bench_full.json, r03z_bench_infer256.json")
+            base["all_cores"] = ("not run by default (opt in with --cpu-all-cores): the sample is a few dozen frames, and with one torch thread per hardware thread of "
+                                 "the 256-thread host the per-layer fork/join of its convolutions dominates; `cores` is the thread count actually used, min(os.cpu_count(), 32)")
         return base
     import numpy as np
     import torch
@@ -257,12 +258,23 @@ def cpu_baseline(sandbox, workload, n_faces, threads=None, all_cores=False):
                 "sample": f"{n_faces} synthetic frames through the CPU oracle's cycle step (numpy FLAME + C rasteriser x3, torch-CPU fp32 autograd through the "
                           f"restated generator and encoders in train mode, no optimiser step; {nthr} threads), 1 warm-up + 3 timed passes, median {med:.2f} s"}
     if workload == "flame512":
+        # the reference's FLAME.forward is torch (einsum / bmm on the host's BLAS): oracle/flame_torch_ref.py restates exactly that op sequence, pinned against
+        # the real class by tests/golden/flame_golden.npz — SURVEY 6 measured the reference class itself at ~5.1 k faces/s on 8 cores; the numpy port
+        # (oracle/flame_ref.py, the parity checker) is timed once beside it
+        from oracle.flame_torch_ref import FlameTorchRef
         p = synth.synth_flame_params(n_faces, seed=5)
+        ft = FlameTorchRef(sandbox).eval()
+        pt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}
+        t0 = time.perf_counter()
+        fr.forward(p)
+        numpy_port_s = time.perf_counter() - t0
 
         def run():
             t0 = time.perf_counter()
-            fr.forward(p)
-            stages["flame"] = time.perf_counter() - t0
+            with torch.no_grad():
+                ft(pt)
+            stages["flame_torch"] = time.perf_counter() - t0
+            stages["flame_numpy_port_once"] = numpy_port_s
     else:
         encr = M.SmirkEncoderRef().eval()
         with torch.no_grad():
@@ -288,19 +300,21 @@ def cpu_baseline(sandbox, workload, n_faces, threads=None, all_cores=False):
                 G.forward(gsd, torch.cat([torch.from_numpy(r["rendered_img"]), masked], 1))
                 stages["generate"] = time.perf_counter() - t3
 
-    run(); run()                            # 2 warm-ups (the first also builds raster_ref.c if needed)
+    run()                                   # warm-ups (the first also builds raster_ref.c if needed)
+    if passes >= 5:
+        run()
     times, keep = [], {}
-    for _ in range(5):
+    for _ in range(max(1, passes)):
         t = time.perf_counter()
         run()
         times.append(time.perf_counter() - t)
         keep = dict(stages) if times[-1] <= min(times) else keep
     med = statistics.median(times)
     what = {"full": "torch-CPU fp32 encoder + generator, numpy FLAME, C rasteriser with OpenMP", "infer256": "torch-CPU fp32 encoder, numpy FLAME, C rasteriser with OpenMP",
-            "flame512": "numpy FLAME"}[workload]
+            "flame512": "torch-CPU fp32 restatement of the reference FLAME.forward, oracle/flame_torch_ref.py"}[workload]
     return {"value": n_faces / med, "unit": "faces/sec", "cores": nthr, "kind": "port", "host_cores": os.cpu_count(),
             "stage_seconds": {k: round(v, 4) for k, v in keep.items()},
-            "sample": f"{n_faces} synthetic frames through the CPU oracle ({what}; {nthr} threads), 2 warm-ups + 5 timed passes, median {med:.2f} s "
+            "sample": f"{n_faces} synthetic frames through the CPU oracle ({what}; {nthr} threads), {2 if passes >= 5 else 1} warm-up(s) + {max(1, passes)} timed passes, median {med:.2f} s "
                       f"(min {min(times):.2f}, max {max(times):.2f})"}
 
 
@@ -359,9 +373,11 @@ def measure_traffic(args):
     return table
 
 
-def rocprofv3_avg(workload, kernel):
+def rocprofv3_avg(workload, kernel, variant=""):
     """rocprofv3 --kernel-trace --stats' own per-launch average of `kernel` for this workload's command line, from the committed summary of the SAME kernel
-    sources (tools/rocprof_summary.py writes the JSON); None-with-reason otherwise."""
+    sources (tools/rocprof_summary.py writes the JSON); None-with-reason otherwise.  variant="_serial": the summary of the SERIAL schedule (`--no-overlap`,
+    the generator's deep section as one whole-batch chain: the state roofline.achieved / frac describe), so that `frac` can be recomputed from profiles/ alone."""
+    workload = workload + variant
     f = os.path.join(REPO, "profiles", f"rocprofv3_kernel_avg_{workload}.json")
     try:
         j = json.load(open(f))
@@ -375,7 +391,9 @@ def rocprofv3_avg(workload, kernel):
         return {"avg_launch_us": None, "why": f"{key} not in {os.path.basename(f)}"}
     return {"avg_launch_us": k["avg_us"], "calls": k["calls"], "command": j.get("command"), "file": "profiles/" + str(j.get("summary_file")),
             "kernel_sources_sha": j["kernel_sources_sha"],
-            "note": "rocprofv3's average over the timed-region schedule (two half-batch chains in the deep section, generator overlapping the next pass's front end)"}
+            "note": ("rocprofv3's average over the serial schedule (--no-overlap, SMIRK_GEN_SPLIT_CHAINS=0: one whole-batch chain, nothing else on the device) - the state "
+                     "`achieved` / `frac` describe: flop_per_launch / this average reproduces `frac` from profiles/ alone" if variant == "_serial" else
+                     "rocprofv3's average over the timed-region schedule (two half-batch chains in the deep section, generator overlapping the next pass's front end)")}
 
 
 def per_rank_batch(args, world):
@@ -639,6 +657,45 @@ class PlumbingWorkload(Workload):
         self.gather.wait()
 
 
+class PlumbingTrainWorkload(Workload):
+    """CPU/gloo stand-in for config 5's data-parallel step, used ONLY by tests/test_distributed_cpu.py: drives the part of TrainWorkload.step that is not
+    kernel work — the bucketed gradient all-reduce of smirk_amd.cycle.allreduce_gradients over the rank group (frozen parameters left out, a missing
+    gradient counted as zero), the optimiser step on the averaged gradients — on a stub network.  Computes nothing of SMIRK; labelled as such."""
+    keys = ()
+
+    def __init__(self, args, dev, rank, world, sandbox):
+        import torch
+        self.B = args.batch if args.batch is not None else (args.global_batch // world if args.global_batch else 64)
+        self.rank, self.world = rank, world
+        torch.manual_seed(0)                                         # identical replicas on every rank, like DDP after its broadcast
+        self.net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 8))
+        for p in self.net[1].parameters():
+            p.requires_grad_(False)                                  # the frozen pose / shape encoders
+        self.params = list(self.net.parameters())
+        self.opt = torch.optim.SGD([p for p in self.params if p.requires_grad], lr=0.1)
+        self.x = torch.arange(self.B * 16, dtype=torch.float32).reshape(self.B, 16) / (self.B * 16) * (rank + 1)
+        self.buckets, self.checked, self.last = 0, [], None
+
+    def step(self):
+        import torch
+        from smirk_amd.cycle import allreduce_gradients
+        self.opt.zero_grad(set_to_none=True)
+        self.net(self.x).square().mean().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in self.params]
+        self.buckets = allreduce_gradients(self.params, bucket_bytes=1024)          # tiny buckets: several all-reduces per step
+        # every rank's replica sees the same inputs scaled by (rank + 1): the averaged gradient can be checked against a local recomputation
+        ref = []
+        for r in range(self.world):
+            net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 8))
+            net.load_state_dict(self.net.state_dict())
+            net(self.x / (self.rank + 1) * (r + 1)).square().mean().backward()
+            ref.append([p.grad for p in net.parameters()])
+        ok = all(torch.allclose(p.grad, sum(g[i] for g in ref) / self.world, rtol=1e-5, atol=1e-7)
+                 for i, p in enumerate(self.params) if p.requires_grad)
+        self.checked.append(bool(ok and all(l is not None for l, p in zip(local, self.params) if p.requires_grad)))
+        self.opt.step()
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass):
     """recs: [(kernel, flop, bytes, ms)] from the library's launch profiler over ONE instrumented pass of a micro-batch."""
@@ -681,7 +738,23 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
                 "traffic": traffic, "bytes_per_launch": by / n,
                 "note": "achieved = algorithmic bytes (unique operands in + out) per launch / HIP-event launch time" if by else
                         "the dispatcher states no algorithmic byte count for this kernel"}
+    if roof["frac"] < 0.05:
+        # a dominant kernel below 5 % of the roof it is priced against is bound by neither: its launches are short dependent steps (one 7 x 7 image per workgroup,
+        # a few hundred workgroups per launch) whose cost is launch + fill + drain latency.  Say so, and report what such a step is made of: how many launches the
+        # pass chains and how long the chain takes end to end (the three backbones run on three streams, so the pass's wall time is its critical path).
+        roof["priced_against"] = {"bound": roof["bound"], "achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"], "frac": roof["frac"]}
+        roof["bound"] = "latency"
+        roof["launches_on_critical_path"] = sum(v[3] for v in per.values())
+        roof["critical_path_us"] = dt_pass * 1e6
+        roof["note"] = ("dominant kernel at < 0.05 of the %s roof: latency-bound (short dependent launches); `achieved` / `peak` / `frac` keep the figure against that roof "
+                        "for the record, the meaningful quantities are launches_on_critical_path (library launches per pass) and critical_path_us (wall time of one pass in "
+                        "the timed region)" % roof["priced_against"]["bound"])
     roof["rocprofv3"] = rocprofv3_avg(workload, dom)
+    if workload == "full":
+        roof["rocprofv3_serial"] = rocprofv3_avg(workload, dom, "_serial")
+        us = roof["rocprofv3_serial"].get("avg_launch_us")
+        if us and roof.get("flop_per_launch"):
+            roof["rocprofv3_serial"]["frac_from_this_average"] = roof["flop_per_launch"] / (us * 1e-6) / (roof["peak"] * 1e12)
     roof.update(launches_per_pass=n, launches_total_per_pass=sum(v[3] for v in per.values()), avg_launch_ms=tm / n * 1e3, traffic_source=traffic_source,
                 kernel_name_source="libsmirk_hip.so launch profiler (smirk_profile_start/stop): the instantiation that was launched, HIP events on its launch stream",
                 kernels={k: {"ms_per_pass": round(v[2] * 1e3, 4), "launches": v[3], **({"tflops": round(v[0] / v[2] / 1e12, 2)} if v[0] > 0 else {}),
@@ -692,13 +765,15 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
 # ------------------------------------------------------------------------------------------------------------------------------
 # "also": the other BASELINE configs, timed in the same process AFTER the headline's timed region (the driver only ever runs `bench.py --gpus 1`)
 # ------------------------------------------------------------------------------------------------------------------------------
-ALSO_SPECS = (   # name, argv of the child run, steps, warmup
-    ("flame512", ["--workload", "flame512"], 50, 10),
-    ("infer256", ["--workload", "infer256"], 20, 5),
-    ("train64_f16x3", ["--workload", "train64", "--train-arith", "f16x3"], 10, 3),
-    ("train64_f16x1", ["--workload", "train64", "--train-arith", "f16x1"], 10, 3),
-    ("full_shard128_collective", ["--workload", "full", "--global-batch", "128", "--force-collective"], 20, 5),
+ALSO_SPECS = (   # name, argv of the child run, steps, warmup, frames of the child's CPU baseline (0: the entry names the line that holds the same CPU path)
+    ("flame512", ["--workload", "flame512"], 50, 10, 512),
+    ("infer256", ["--workload", "infer256"], 20, 5, 24),
+    ("train64_f16x3", ["--workload", "train64", "--train-arith", "f16x3"], 10, 3, 8),
+    ("train64_f16x1", ["--workload", "train64", "--train-arith", "f16x1"], 10, 3, 0),
+    ("full_shard128_collective", ["--workload", "full", "--global-batch", "128", "--force-collective"], 20, 5, 0),
 )
+ALSO_CPU_SAME_AS = {"train64_f16x1": "also.train64_f16x3.cpu_baseline (the CPU path has one arithmetic: torch-CPU fp32 autograd)",
+                    "full_shard128_collective": "cpu_baseline of this line (same workload, config 4)"}
 
 
 def run_also(args):
@@ -707,11 +782,13 @@ def run_also(args):
     would run by hand, so the numbers are the stand-alone numbers.  (Round 5 first ran them inside this process: after the 1024-frame headline had been through the
     allocator every streaming kernel of the later workloads ran at ~0.65 of its stand-alone rate — train64 67.5 ms in-process against 43.6 ms alone on the same box,
     infer256 38.8 k against 43.5 k, profiles/r05b_* — so the in-process numbers described the bench process, not the library.)  Each child computes its own roofline
-    from the launch profiler (no counter passes, no CPU baseline); an entry that fails reports the error instead of taking the headline down."""
+    from the launch profiler (no counter passes) and times its own bounded CPU baseline after its timed region (flame512: 512 parameter vectors through the torch
+    restatement of the reference FLAME.forward; infer256: 24 frames; train64: 8 frames, shared by both arithmetics — about 30 s in all); an entry that fails reports the error instead of taking the headline down."""
     out, t_all = {}, time.perf_counter()
-    for name, argv, steps, warmup in ALSO_SPECS:
+    for name, argv, steps, warmup, cpu_faces in ALSO_SPECS:
         t_entry = time.perf_counter()
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", "0", "--no-also",
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off",
+                                                                    "--cpu-faces", str(cpu_faces if args.cpu_faces > 0 else 0), "--cpu-passes", "3", "--no-also",
                                                                     "--flame-basis", args.flame_basis]
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=REPO)
@@ -725,7 +802,11 @@ def run_also(args):
                  "host_enqueue_ms_one_step_idle_queue": j.get("host_enqueue_ms_one_step_idle_queue"),
                  "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_pass", "avg_launch_ms",
                                                        "profiled_kernel_ms_per_pass")},
-                 "launches_per_step": roof.get("launches_total_per_pass")}
+                 "launches_per_step": roof.get("launches_total_per_pass"),
+                 "cpu_baseline": j.get("cpu_baseline") or ALSO_CPU_SAME_AS.get(name)}
+            for k in ("critical_path_us", "launches_on_critical_path"):
+                if roof.get(k) is not None:
+                    e["roofline"][k] = roof[k]
             out[name] = e
         except Exception as ex:                     # noqa: BLE001 — the headline line must still be produced
             out[name] = {"error": f"{type(ex).__name__}: {str(ex)[:400]}"}
@@ -771,7 +852,7 @@ def main():
 
     from smirk_amd import _lib as L
     sandbox = tempfile.mkdtemp(prefix=f"smirk_bench_r{rank}_")
-    cls = PlumbingWorkload if args.plumbing_test else {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload, "train64": TrainWorkload}[args.workload]
+    cls = (PlumbingTrainWorkload if args.workload == "train64" else PlumbingWorkload) if args.plumbing_test else {"full": FullWorkload, "infer256": InferWorkload, "flame512": FlameWorkload, "train64": TrainWorkload}[args.workload]
     wl = cls(args, dev, rank, world, sandbox)
 
     def sync():
@@ -877,7 +958,7 @@ def main():
         value = faces / dt
         cpu = None
         if world == 1 and args.cpu_faces > 0 and not args.plumbing_test:
-            cpu = cpu_baseline(sandbox, args.workload, args.cpu_faces if args.workload != "flame512" else 512, all_cores=args.cpu_all_cores)
+            cpu = cpu_baseline(sandbox, args.workload, args.cpu_faces if args.workload != "flame512" else 512, all_cores=args.cpu_all_cores, passes=args.cpu_passes)
         weak = args.batch is not None or (args.workload == "train64" and args.global_batch is None)
         flop_face = {"full": FLOP_PER_FACE, "infer256": FLOP_PER_FACE_INFER, "flame512": FLOP_PER_FACE_FLAME, "train64": FLOP_PER_FACE_TRAIN}[args.workload]
         gen_prec = getattr(getattr(wl, "gen", None), "precision", None)
@@ -903,7 +984,7 @@ def main():
                        "collective": ("async all_gather_into_tensor(vertices, rendered_img, reconstructed_img) per micro-batch" if world > 1 else
                                       "async all_gather_into_tensor(...) per micro-batch through a world-size-1 RCCL group (--force-collective)"
                                       if getattr(args, "force_collective", False) else "none (1 GPU)")
-                       if args.workload == "full" or args.plumbing_test else
+                       if args.workload == "full" or (args.plumbing_test and args.workload != "train64") else
                        (f"bucketed all_reduce of the gradients after backward ({getattr(wl, 'buckets', 0)} buckets of <= 64 MiB)" if world > 1 else "none (1 GPU)")
                        if args.workload == "train64" else "none (outputs stay on the rank)",
                        "weights": "random-init (He) reference architecture, encoder heads rescaled to the trained network's parameter ranges; no checkpoint offline; outputs asserted finite",
@@ -926,7 +1007,11 @@ def main():
             "output_stats": stats, "roofline": roof, "cpu_baseline": cpu}
         if also is not None:
             line["also"] = also
-        if args.plumbing_test:
+        if args.plumbing_test and args.workload == "train64":
+            sd = wl.net.state_dict()
+            line["plumbing"] = {"buckets": wl.buckets, "averaged_gradients_ok": wl.checked, "steps_checked": len(wl.checked),
+                                "weights_checksum": float(sum(v.double().sum() for v in sd.values()))}
+        elif args.plumbing_test:
             line["plumbing"] = {"gathered_ids_last": wl.seen[-1], "micro_batches_per_step": len(wl.slices), "gathers": len(wl.seen)}
         try:                                 # RCCL prints its version banner through C stdio: flush it out BEFORE the JSON line, which stays the last line on stdout
             import ctypes

@@ -30,6 +30,14 @@ extern "C" {
 #define SMIRK_ERR_UNSUPPORTED (-4)
 
 const char* smirk_strerror(int code);
+/* Split-fp16 range flag.  Activations are stored as fp16 (hi, lo) pairs: a value of magnitude >= 65520 cannot be carried (hi becomes inf) and every
+ * later layer would silently turn it into inf / NaN pixels — with the reference's fp32 tensors (smirk_generator.py:51-86, smirk_encoder.py:14-133) the same
+ * checkpoint simply works.  Every kernel that writes the storage format audits what it stores and sets ONE sticky host-visible word; no entry of this library
+ * synchronises to look at it.  peek: non-zero once any kernel THAT HAS FINISHED saw such a value since the last clear (the Python modules call it at the start of
+ * each forward and raise SmirkHipError: "raise on the next call"; after a synchronisation of the caller's own it is exact).  clear: re-arm. */
+unsigned smirk_range_flag_peek(void);
+void smirk_range_flag_clear(void);
+
 /* ABI version of this header (bumped on any signature change). */
 int smirk_abi_version(void);
 
@@ -465,6 +473,9 @@ int smirk_conv_wgrad_f16x1(const void* dz, const void* x, float* dw, int B, int 
  * x1 != 0 asks for the f16x1 arithmetic where the fp16 kernels serve the call (falls back to the f32-class kernels otherwise, like the Python caller did). */
 int smirk_conv_wgrad_param(const void* dz, const void* x, float* dw_param, int B, int H, int W, int Cout, int Cin, int KH, int reflect, int layout, int cin_total,
                            int cin_off, int cin_real, int x1, void* ws, size_t ws_bytes, void* stream);
+/* number of smirk_conv_wgrad_param calls since load that asked for x1 and were served by the f32-class kernels instead: lets the caller tell the user that a
+ * step declared f16x1 (the reference: bf16 autocast, base_trainer.py / smirk_trainer.py:349-376) mixed arithmetics, instead of doing so silently */
+unsigned long long smirk_conv_wgrad_x1_fallbacks(void);
 
 /* ---- train-mode SmirkEncoder backbones (csrc/train_encoder.hip): what `self.train()` + autograd does to the timm
  * tf_mobilenetv3_{small,large}_minimal_100 feature extractors of smirk_encoder.py:7-12 (pointwise convolutions and BatchNorm reuse the entries above).

@@ -48,4 +48,14 @@ from .smirk_generator import SmirkGenerator  # noqa: F401
 from . import masking  # noqa: F401  (drop-in for src/utils/masking.py)
 from .video import VideoPipeline  # noqa: F401  (demo_video.py's frame loop, batched + streamed)
 
-__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib", "masking", "VideoPipeline"]
+
+
+def check_numerics():
+    """Synchronise the device and raise SmirkHipError if any kernel of this library stored a value that the split-fp16 activation format cannot carry
+    (|x| >= 65520 or a non-finite input) since the last check.  The modules perform the same check — without synchronising — at the start of every forward, so an
+    overflow is reported by the next call at the latest; call this after the LAST forward of a job (e.g. before writing results to disk)."""
+    from ._lib import raise_if_range_tripped
+    raise_if_range_tripped("smirk_amd.check_numerics", synchronize=True)
+
+
+__all__ = ["FLAME", "Renderer", "SmirkEncoder", "SmirkGenerator", "SmirkHipError", "lib", "masking", "VideoPipeline", "check_numerics"]

@@ -11,7 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
-ABI_VERSION = 10
+ABI_VERSION = 11
 SMIRK_OK, SMIRK_ERR_BAD_ARG, SMIRK_ERR_WORKSPACE, SMIRK_ERR_LAUNCH, SMIRK_ERR_UNSUPPORTED = 0, -1, -2, -3, -4      # include/smirk_hip.h
 
 _p = C.c_void_p
@@ -72,6 +72,8 @@ OUT_NHWC, OUT_CONVT2X2 = 0, 1
 _SIGS = {
     "smirk_strerror": (C.c_char_p, [_i]),
     "smirk_abi_version": (_i, []),
+    "smirk_range_flag_peek": (C.c_uint, []),
+    "smirk_range_flag_clear": (None, []),
     "smirk_flame_workspace_bytes": (_sz, [C.POINTER(SmirkFlameModel), _i]),
     "smirk_flame_forward": (_i, [C.POINTER(SmirkFlameModel), _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                  _p, _p, _sz, _p]),
@@ -151,6 +153,7 @@ _SIGS = {
     "smirk_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_conv_wgrad_f16x1": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_conv_wgrad_param": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_conv_wgrad_x1_fallbacks": (C.c_ulonglong, []),
     "smirk_pack_conv_weights_batch_split16": (_i, [_p, _i, C.c_ulonglong, _p]),
     "smirk_pack_conv_weights_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_stem_conv_s2_raw_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -194,6 +197,22 @@ def lib():
 def check(code):
     if code != 0:
         raise SmirkHipError(f"libsmirk_hip: {lib().smirk_strerror(code).decode()} ({code})")
+
+
+def raise_if_range_tripped(where, synchronize=False):
+    """The split-fp16 storage format carries |x| < 65520 only (its `hi` half is an fp16).  Every kernel that writes it audits what it stores and sets one sticky
+    host-pinned word (include/smirk_hip.h smirk_range_flag_peek); this reads that word — a plain host load, no device synchronisation unless asked for — and
+    raises once it is set.  The modules call it at the START of every forward, so an overflow in call N is reported by call N + 1 at the latest (or by
+    smirk_amd.check_numerics(), which synchronises first).  The reference computes in fp32 and has no such limit: a checkpoint whose activations leave the
+    fp16 range must run SmirkGenerator.precision = "f32" (exact-fp32 kernels) instead."""
+    if synchronize:
+        torch.cuda.synchronize()
+    L = lib()
+    if L.smirk_range_flag_peek():
+        L.smirk_range_flag_clear()
+        raise SmirkHipError(f"{where}: an activation left the range of the split-fp16 storage format (|x| >= 65520, or a non-finite input) in a kernel that ran "
+                            "before this call — its output and everything computed from it are invalid (inf / NaN).  Badly scaled weights or inputs; the exact-fp32 "
+                            "generator kernels (SmirkGenerator.precision = 'f32') have no such limit.  The flag has been cleared.")
 
 
 def stream_ptr():

@@ -12,7 +12,32 @@ extern "C" const char* smirk_strerror(int code) {
     }
 }
 
-extern "C" int smirk_abi_version(void) { return 10; }
+extern "C" int smirk_abi_version(void) { return 11; }
+
+// ---- split-fp16 range flag (common.h: smirk_range_audit8) -------------------------------------------------------------------------------
+// ONE host-pinned, device-mapped word per process.  Kernels store a 1 into it (system-scope store, cold path) when a value they are about to split into the
+// storage format would overflow the fp16 `hi` half; the host READS it with a plain load — no stream or device synchronisation — when the next forward of a
+// module starts (or when the user asks, smirk_range_flag_peek after a synchronisation of their own).  Sticky until smirk_range_flag_clear().
+#include <mutex>
+namespace {
+std::once_flag g_range_once;
+unsigned* g_range_host = nullptr;
+unsigned* g_range_dev = nullptr;
+}  // namespace
+unsigned* smirk_range_flag_device_ptr() {
+    std::call_once(g_range_once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !h) { (void)hipGetLastError(); return; }
+        *(volatile unsigned*)h = 0u;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_range_host = (unsigned*)h;
+        g_range_dev = (unsigned*)d;
+    });
+    return g_range_dev;
+}
+extern "C" unsigned smirk_range_flag_peek(void) { return g_range_host ? *(volatile unsigned*)g_range_host : 0u; }
+extern "C" void smirk_range_flag_clear(void) { if (g_range_host) *(volatile unsigned*)g_range_host = 0u; }
 
 // ---- launch profiler ---------------------------------------------------------------------------------------------------------------
 #include <mutex>

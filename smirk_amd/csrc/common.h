@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/smirk_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,6 +36,43 @@ __device__ __forceinline__ void smirk_split2(float a, float b, smirk_half2& hi, 
 
 #define SMIRK_WAVE 64
 
+// ---- split-fp16 range audit (fail loudly instead of propagating inf / NaN) ----------------------------------------------------------------------------------
+// hi is an fp16: a value of magnitude >= 65520 becomes +-inf when it is stored, and every later layer turns it into inf / NaN pixels without any error (a badly
+// scaled checkpoint is the case nobody can test offline).  Every site that SPLITS fp32 results into the storage format audits the eight values it is about to
+// store: four v_max3_f32 on |v| + one compare + one never-taken branch per 8-channel group; the cold path stores a 1 into ONE host-pinned, device-mapped word
+// (capi.hip) that the host reads — without any synchronisation — at the start of the NEXT forward call of a module (smirk_amd/_lib.py raise_if_range_tripped).
+// fmaxf drops NaNs, which is fine here: a NaN inside the network is the child of an inf that was flagged where it was produced; NaNs arriving from OUTSIDE are caught
+// by smirk_range_audit1 (`!(|v| < limit)` is true for NaN) in the kernels that convert images / parameters into the storage format.
+// The pointer to that word is a per-translation-unit __device__ variable bound lazily by the first launch of each unit on each device (SMIRK_LAUNCH below).
+static __device__ __attribute__((unused)) unsigned* smirk_range_flag_dev;
+#define SMIRK_F16_RANGE_LIMIT 65520.0f
+__device__ __forceinline__ void smirk_range_trip() {
+    unsigned* f = smirk_range_flag_dev;
+    if (f) __hip_atomic_store(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void smirk_range_audit8(const float* v) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                          fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+    if (__builtin_expect(!(m < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
+}
+__device__ __forceinline__ void smirk_range_audit4(const float* v) {
+    const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (__builtin_expect(!(m < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
+}
+__device__ __forceinline__ void smirk_range_audit1(float v) {                  // NaN-catching form (inputs from outside the library)
+    if (__builtin_expect(!(fabsf(v) < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
+}
+unsigned* smirk_range_flag_device_ptr();                                        // capi.hip: device address of the host-pinned word (nullptr if it cannot be mapped)
+static inline void smirk_range_bind_tu() {
+    static std::atomic<unsigned long long> bound{0};                            // one bit per device, per translation unit
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return; }
+    if ((bound.load(std::memory_order_relaxed) >> dev) & 1ull) return;
+    unsigned* p = smirk_range_flag_device_ptr();
+    if (p && hipMemcpyToSymbol(HIP_SYMBOL(smirk_range_flag_dev), &p, sizeof(p)) != hipSuccess) (void)hipGetLastError();   // (a unit without audited kernels has no such symbol)
+    bound.fetch_or(1ull << dev, std::memory_order_relaxed);
+}
+
 static inline size_t smirk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static inline int smirk_launch_status() {
@@ -62,6 +101,7 @@ struct SmirkLaunchScope {
 };
 #define SMIRK_LAUNCH(kernel, grid, block, lds, st, ...)                                   \
     do {                                                                                  \
+        smirk_range_bind_tu();                                                            \
         SmirkLaunchScope smirk_launch_scope_(#kernel, (hipStream_t)(st));                 \
         hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                    \
     } while (0)

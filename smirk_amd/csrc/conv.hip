@@ -904,6 +904,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
             float x = 0.f;
             if (c < Ca) x = a[(b * Ca + c) * HW + p];
             else if (c < Ca + Cb) x = b2[(b * Cb + (c - Ca)) * HW + p];
+            smirk_range_audit1(x);                                // the network INPUT: the one place a NaN can enter from outside (`!(|x| < limit)` catches it)
             v[c] = x;
         }
         half8 hi, lo;

@@ -35,6 +35,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 
 // 8 fp32 values -> split-fp16 group: out_hi = fp16(v), out_lo = fp16((v - hi) * 2^11)
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
+    smirk_range_audit8(v);
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
         smirk_half2 h, l;

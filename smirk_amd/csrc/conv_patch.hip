@@ -94,6 +94,7 @@ __device__ __forceinline__ void frag_ready(const half8& a0, const half8& a1, con
 }
 
 __device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
+    smirk_range_audit8(v);
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
         smirk_half2 h, l;

@@ -89,6 +89,7 @@ __device__ __forceinline__ void e1_split2(float a, float b, unsigned& hi, unsign
 // operations back to back through ONE temporary register: ~9 cycles per VALU instruction, 4-6 k cycles per epilogue (tools/enc1_timeline.py).
 #define E1_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ void e1_split8(float (&y)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
+    smirk_range_audit8(y);
     half2v h[4];
     float d[8];
 #pragma unroll

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
             }
             if (oy < a.Ho && ox < a.Wo) {
                 half8 hi, lo;
+                smirk_range_audit8(acc);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     _Float16 h, l;

@@ -8,6 +8,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // split-fp16 activation format (see conv.hip): 8 channels = 8 hi halves + 8 lo halves; value = hi + lo * 2^-11
 __device__ __forceinline__ void enc_split8(const float* v, half8& hi, half8& lo) {
+    smirk_range_audit8(v);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         _Float16 h, l;

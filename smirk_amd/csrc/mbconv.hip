@@ -256,13 +256,16 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
                     }
                 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                 half4 hi, lo;
+                float amax = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = fmaxf(acc[k] * s2[k] + b2[k], 0.f);
+                    amax = fmaxf(amax, v);
                     _Float16 h, l;
                     smirk_split1(v, h, l);
                     hi[k] = h; lo[k] = l;
                 }
+                if (__builtin_expect(!(amax < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
                 char* d = Ds + p * DSB + (c4 >> 1) * 32 + (c4 & 1) * 8;
                 *(half4*)d = hi;
                 *(half4*)(d + 16) = lo;
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
                 for (int k = 0; k < 8; ++k) v[k] += mb_join(hi[k], lo[k]);
             }
             half8 hi, lo;
+            smirk_range_audit8(v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 _Float16 h, l;

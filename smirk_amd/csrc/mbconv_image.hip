@@ -276,13 +276,16 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
                     }
                 const f32x4 sa = *(const f32x4*)(wc + 9 * 32 + c8), sb = *(const f32x4*)(wc + 9 * 32 + c8 + 4);
                 const f32x4 ba = *(const f32x4*)(wc + 10 * 32 + c8), bb = *(const f32x4*)(wc + 10 * 32 + c8 + 4);
+                float amax = 0.f;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float v = fmaxf(acc[q] * (q < 4 ? sa[q & 3] : sb[q & 3]) + (q < 4 ? ba[q & 3] : bb[q & 3]), 0.f);
+                    amax = fmaxf(amax, v);
                     _Float16 h, l;
                     smirk_split1(v, h, l);
                     dh[s][q] = h; dl[s][q] = l;
                 }
+                if (__builtin_expect(!(amax < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
             }
         }
         if (more) store_stage(c + 1);                   // the other Wp / Wc buffer: last read in chunk c-1, read next after two barriers
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
                             for (int k = 0; k < 8; ++k) v[k] += (float)hi[k] + (float)lo[k] * (1.0f / 2048.0f);
                         }
                         half8 hi, lo;
+                        smirk_range_audit8(v);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             _Float16 h, l;

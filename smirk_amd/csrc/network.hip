@@ -12,6 +12,8 @@
 //   * everything else rotates through three scratch slots sized for the largest temporary (a layer reads at most two temporaries —
 //     input and residual — and writes one).
 // No allocation, no synchronisation; every pointer is a device pointer except the weight structs (host structs of device pointers).
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -161,8 +163,32 @@ extern "C" int smirk_generator_forward(const SmirkGeneratorWeights* w, const flo
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     if (nchain > 1) {
-        thread_local hipStream_t side_dev[64][2] = {};
-        thread_local hipEvent_t ev_dev[64][3] = {};
+        // RAII: a host thread that ends releases its side streams and events (a thread pool of short-lived workers leaked 2 streams + 3 events per thread; advisor r05).
+        // The destructor runs at thread exit; work still queued on a side stream completes first (hipStreamDestroy defers the release until the stream drains).
+        struct ChainResources {
+            hipStream_t side[64][2] = {};
+            hipEvent_t ev[64][3] = {};
+            ~ChainResources() {
+                // the MAIN thread's thread_locals are destroyed inside exit(), where the HIP runtime may already be shutting down: the process exit reclaims them
+                if ((long)syscall(SYS_gettid) == (long)getpid()) return;
+                int cur = 0;
+                const bool have = hipGetDevice(&cur) == hipSuccess;
+                for (int d = 0; d < 64; ++d) {
+                    bool any = false;
+                    for (int k = 0; k < 2; ++k) any = any || side[d][k];
+                    for (int k = 0; k < 3; ++k) any = any || ev[d][k];
+                    if (!any) continue;
+                    if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+                    for (int k = 0; k < 2; ++k) if (side[d][k]) (void)hipStreamDestroy(side[d][k]);
+                    for (int k = 0; k < 3; ++k) if (ev[d][k]) (void)hipEventDestroy(ev[d][k]);
+                }
+                if (have) (void)hipSetDevice(cur);
+                (void)hipGetLastError();
+            }
+        };
+        thread_local ChainResources chain_res;
+        hipStream_t (&side_dev)[64][2] = chain_res.side;
+        hipEvent_t (&ev_dev)[64][3] = chain_res.ev;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); nchain = 1; }
         else {

@@ -14,6 +14,7 @@
 //                      (925 MB at B=256 in the reference) + add_directionlight (renderer.py:239-250).
 //
 // Bound: HBM/L2 (integer + fp32 scan work).  Algorithmic bytes per face (image): verts in 60 KB, image out 602 KB.
+#include <atomic>
 #include <stdlib.h>
 
 #include "common.h"
@@ -491,6 +492,19 @@ extern "C" int smirk_render_forward(const SmirkRenderMesh* mesh, int B, int H, i
 #else
     const int ablate = 0;
 #endif
+    if (smem > 64 * 1024) {
+        // the four per-wave bin lists grow with the mesh (2 bytes per face): beyond ~27 k faces the dynamic LDS passes the 64 KB a launch gets by default.
+        // gfx950 has 160 KB per workgroup: raise this kernel's limit once per process (the largest size asked so far), refuse what cannot fit at all.
+        if (smem > 150 * 1024) return SMIRK_ERR_UNSUPPORTED;
+        static std::atomic<size_t> raised{0};
+        if (raised.load(std::memory_order_relaxed) < smem) {
+            if (hipFuncSetAttribute((const void*)raster_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+                (void)hipGetLastError();
+                return SMIRK_ERR_UNSUPPORTED;
+            }
+            raised.store(smem, std::memory_order_relaxed);
+        }
+    }
     SMIRK_LAUNCH(raster_tile, dim3(tiles, B), dim3(256), smem, st, d, B, H, W, frec, fbox, nvalid, nrm, img,
                        (long long*)pix_to_face, bary, zbuf, qmax, ablate);
     return smirk_launch_status();

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -1167,6 +1168,7 @@ static bool wgrad_halo_ok(int W, int Cout, int Cin, int KH, int reflect) {
 // $SMIRK_WGRAD_F16: "0" = exact-fp32 MFMA kernel (wgrad_kernel), "1" / "2" = split-fp16 x3 kernel with 1 / 2 chunks per barrier (default 2);
 // "+16" (17 / 18) selects the alternative lane geometry of the LDS transpose read (diagnostic)
 static int g_wgrad_mode_override = -1;
+static std::atomic<unsigned long long> g_wgrad_x1_fallbacks{0};
 static int wgrad_f16_mode() {
     static const int mode = [] { const char* e = getenv("SMIRK_WGRAD_F16"); return e ? atoi(e) : SMIRK_WGRAD_F16_DEFAULT; }();
     return g_wgrad_mode_override >= 0 ? g_wgrad_mode_override : mode;
@@ -1222,9 +1224,15 @@ extern "C" int smirk_conv_wgrad_param(const void* dz, const void* x, float* dw_p
     }
     const WgradLayout L{layout, KH * KH, Cin, cin_total, cin_off, cin_real};
     int rc = x1 ? conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 1, L) : SMIRK_ERR_UNSUPPORTED;
-    if (rc == SMIRK_ERR_UNSUPPORTED) rc = conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 0, L);
+    if (rc == SMIRK_ERR_UNSUPPORTED) {
+        if (x1) g_wgrad_x1_fallbacks.fetch_add(1, std::memory_order_relaxed);     // a step that declared f16x1 ran this layer in the f32-class arithmetic: countable
+        rc = conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 0, L);
+    }
     return rc;
 }
+/* how many smirk_conv_wgrad_param calls asked for the one-MFMA arithmetic (x1) and were served by the f32-class kernels instead (operands >= 2 GiB, or
+ * $SMIRK_WGRAD_F16=0) since the library was loaded: the Python wrapper warns once when this moves, so a step never mixes arithmetics silently */
+extern "C" unsigned long long smirk_conv_wgrad_x1_fallbacks(void) { return g_wgrad_x1_fallbacks.load(std::memory_order_relaxed); }
 static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                            void* stream, int x1, WgradLayout L) {
     if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || Cout % 8 || Cin % 8 || Cout <= 0 || Cin <= 0 || (KH != 1 && KH != 3)) return SMIRK_ERR_BAD_ARG;
@@ -1237,10 +1245,10 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         h.B = B; h.H = H; h.W = W; h.Cout = Cout; h.Cin = Cin; h.KH = 3; h.pad = 1; h.reflect = 0;
         h.chunks_per_split = (int)((chunks + nsplit - 1) / nsplit);          // W % 16 == 0: a 16-pixel chunk never crosses a row
         hipStream_t hs = (hipStream_t)stream;
-        smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
         const bool fits32h = npix * Cout * 4 < (1ll << 31) && npix * Cin * 4 < (1ll << 31);     // 32-bit buffer offsets (see below)
         const int mode = fits32h ? wgrad_f16_mode() : 0;
-        if (x1 && !mode) return SMIRK_ERR_UNSUPPORTED;
+        if (x1 && !mode) return SMIRK_ERR_UNSUPPORTED;                       // (before smirk_prof_next: a refused call leaves no pending profile label)
+        smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
         if (mode) {                                                          // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
             const int trmap = (mode >> 4) & 1;
             if (x1) {
@@ -1267,11 +1275,11 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
     hipStream_t st = (hipStream_t)stream;
     const int TM = Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
     const dim3 grid((Cout + TM - 1) / TM, (N + 127) / 128, nsplit);
-    smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
     // the split-fp16 kernel fetches through buffer resources with 32-bit offsets: operands of 2 GiB and more take the exact-fp32 kernel (64-bit pointers)
     const bool fits32 = npix * Cout * 4 < (1ll << 31) && npix * Cin * 4 < (1ll << 31);
     const int mode = fits32 ? wgrad_f16_mode() : 0;
     if (x1 && !mode) return SMIRK_ERR_UNSUPPORTED;
+    smirk_prof_next(nullptr, 2.0 * (double)npix * Cout * N, 0.0);
     if (mode) {                                                              // split-fp16 x3 on the fp16 matrix pipe (LDS transpose reads)
         const int trmap = (mode >> 4) & 1;
         if (x1) {                                                            // (always two chunks per barrier: the measured default)

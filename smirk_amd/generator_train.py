@@ -42,6 +42,25 @@ def _pack_dgrad(w, cout_pad=None):
     return _split16(w.reshape(w.shape[0], -1).contiguous())
 
 
+_X1_FALLBACK_WARNED = False
+
+
+def _warn_x1_fallback(B, H, W, cout, cin, k):
+    """train_arith = "f16x1" asked for, but this layer's weight gradient ran in the f32-class arithmetic (the fp16 weight-gradient kernels address their operands
+    with 32-bit offsets: tensors of 2 GiB and more, or $SMIRK_WGRAD_F16=0, take the f32-class kernels).  More accurate, slower — and said once, not silently."""
+    global _X1_FALLBACK_WARNED
+    if not _X1_FALLBACK_WARNED:
+        _X1_FALLBACK_WARNED = True
+        import warnings
+        warnings.warn(f"smirk_amd: train_arith='f16x1' but the weight gradient of a {k}x{k} conv ({cin}->{cout} at B={B}, {H}x{W}) was computed by the f32-class "
+                      "kernels (operand >= 2 GiB or SMIRK_WGRAD_F16=0); further occurrences are not reported", RuntimeWarning, stacklevel=3)
+
+
+def _grad_like(weight):
+    """gradient buffer in the parameter's SHAPE, contiguous fp32 whatever the parameter's memory format (the C entry writes the plain row-major layout)"""
+    return torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+
+
 class _Ops:
     """thin stateful wrapper over the C entries: one reduction workspace, the launch stream, and conv descriptors"""
 
@@ -146,6 +165,8 @@ class _Ops:
         args = (P(dz), P(x), P(dw), B, H, W, cout, cin, k, int(reflect), P(self.wg_ws, torch.uint8), self.wg_ws.numel(), self.st)
         rc = self.lib.smirk_conv_wgrad_f16x1(*args) if self.x1 else L.SMIRK_ERR_UNSUPPORTED
         if rc == L.SMIRK_ERR_UNSUPPORTED:                # (f16x1 needs the fp16 weight-gradient kernels: operands >= 2 GiB take the exact-fp32 kernel)
+            if self.x1:
+                _warn_x1_fallback(B, H, W, cout, cin, k)
             rc = self.lib.smirk_conv_wgrad_f32(*args)
         L.check(rc)
         return dw
@@ -158,8 +179,11 @@ class _Ops:
             self.wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         P = L.ptr
         cin_total = out.shape[1] if layout == 1 else 0
+        before = self.lib.smirk_conv_wgrad_x1_fallbacks() if self.x1 else 0
         L.check(self.lib.smirk_conv_wgrad_param(P(dz), P(x), P(out), B, H, W, cout, cin, k, int(reflect), layout, cin_total, cin_off,
                                                 cin if cin_real is None else cin_real, int(self.x1), P(self.wg_ws, torch.uint8), self.wg_ws.numel(), self.st))
+        if self.x1 and self.lib.smirk_conv_wgrad_x1_fallbacks() != before:
+            _warn_x1_fallback(B, H, W, cout, cin, k)
         return out
 
     def colsum(self, x):
@@ -365,7 +389,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
             if dg2 is not None:
                 grads[id(n2.weight)], grads[id(n2.bias)] = dg2, db2
             if need(c2.weight):
-                grads[id(c2.weight)] = ops.wgrad_param(dz2, y1, B, h, w, c, c, 3, torch.empty_like(c2.weight, dtype=torch.float32))
+                grads[id(c2.weight)] = ops.wgrad_param(dz2, y1, B, h, w, c, c, 3, _grad_like(c2.weight))
             dy1 = ops.conv(dz2, None, wd2, B, h, w, c)
             dz1, dg1, db1 = ops.bn_backward(z1, dy1, n1, mu1, iv1, True)
             if dg1 is not None:
@@ -373,13 +397,17 @@ class GeneratorTrainFunction(torch.autograd.Function):
             c0 = x0.shape[-1]
             if x1 is None:
                 if need(c1.weight):                                       # (the network input is padded 6 -> 8 channels: the two padded ones are dropped)
-                    grads[id(c1.weight)] = ops.wgrad_param(dz1, x0, B, h, w, c, c0, 3, torch.empty_like(c1.weight, dtype=torch.float32), cin_real=c1.weight.shape[1])
+                    if c1.weight.shape[1] > c0:
+                        raise L.SmirkHipError(f"conv expects {c1.weight.shape[1]} input channels, its source carries {c0}")
+                    grads[id(c1.weight)] = ops.wgrad_param(dz1, x0, B, h, w, c, c0, 3, _grad_like(c1.weight), cin_real=c1.weight.shape[1])
                 if rec is tape[0] and not want_dx:                        # the network input needs no gradient (cycle path: it is detached)
                     return None, None
                 return ops.conv(dz1, None, wd1a, B, h, w, c0), None
             cc1 = x1.shape[-1]
             if need(c1.weight):                                           # torch.cat((up, skip), 1): channels of source 0 first, both into one tensor
-                gw = torch.empty_like(c1.weight, dtype=torch.float32)
+                if c0 + cc1 != c1.weight.shape[1]:                        # every channel of the parameter must be written by one of the two calls
+                    raise L.SmirkHipError(f"decoder conv expects {c1.weight.shape[1]} input channels, its two sources carry {c0} + {cc1}")
+                gw = _grad_like(c1.weight)
                 ops.wgrad_param(dz1, x0, B, h, w, c, c0, 3, gw, cin_off=0)
                 ops.wgrad_param(dz1, x1, B, h, w, c, cc1, 3, gw, cin_off=c0)
                 grads[id(c1.weight)] = gw
@@ -405,7 +433,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 if need(up.bias):
                     grads[id(up.bias)] = ops.colsum(g)
                 if need(up.weight):                                        # packed [Cin][(dy,dx,co)] -> the parameter's [Cin][Cout][2][2] in the reduction itself
-                    grads[id(up.weight)] = ops.wgrad_param(xin_, s2d, B, h, w, cin, 4 * cout, 1, torch.empty_like(up.weight, dtype=torch.float32), layout=2)
+                    grads[id(up.weight)] = ops.wgrad_param(xin_, s2d, B, h, w, cin, 4 * cout, 1, _grad_like(up.weight), layout=2)
                 wd = _split16(up.weight.detach().float().permute(0, 2, 3, 1).reshape(cin, 4 * cout).contiguous())
                 g = ops.conv(s2d, None, wd, B, h, w, cin, k=1)
             elif kind == "res":
@@ -414,7 +442,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 if dgb is not None:
                     grads[id(nbv.weight)], grads[id(nbv.bias)] = dgb, dbb
                 if need(cbv.weight):
-                    grads[id(cbv.weight)] = ops.wgrad_param(dzb, ya, B, h, w, c, c, 3, torch.empty_like(cbv.weight, dtype=torch.float32), reflect=True)
+                    grads[id(cbv.weight)] = ops.wgrad_param(dzb, ya, B, h, w, c, c, 3, _grad_like(cbv.weight), reflect=True)
                 dpad = ops.conv(dzb, None, wdb, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 dya = torch.empty_like(ya)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), None, L.ptr(dya), B, h, w, c, st))
@@ -422,7 +450,7 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 if dga is not None:
                     grads[id(na.weight)], grads[id(na.bias)] = dga, dba
                 if need(ca.weight):
-                    grads[id(ca.weight)] = ops.wgrad_param(dza, bin_, B, h, w, c, c, 3, torch.empty_like(ca.weight, dtype=torch.float32), reflect=True)
+                    grads[id(ca.weight)] = ops.wgrad_param(dza, bin_, B, h, w, c, c, 3, _grad_like(ca.weight), reflect=True)
                 dpad = ops.conv(dza, None, wda, B, h, w, c, pad=2, out_hw=(h + 2, w + 2))
                 gin = torch.empty_like(bin_)
                 L.check(lib.smirk_reflect_pad1_backward_split16(L.ptr(dpad), L.ptr(g), L.ptr(gin), B, h, w, c, st))     # + the identity branch

@@ -126,7 +126,14 @@ class MobileNetV3Features(nn.Module):
         split = PRECISION == "f16x3"
         self._split = split
         pw32 = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, conv.in_channels).contiguous()
-        pw = (lambda conv: _split16(pw32(conv))) if split else pw32
+
+        def pw16(conv):                                          # a weight the fp16 `hi` half cannot carry is refused when the image is built
+            w = pw32(conv)
+            big = float(w.abs().max()) if w.numel() else 0.0
+            if not big < 65504.0:
+                raise L.SmirkHipError(f"MobileNetV3 pointwise weight with |w| = {big:.4g} does not fit the split-fp16 format (|x| < 65504)")
+            return _split16(w)
+        pw = pw16 if split else pw32
         dw = lambda conv: conv.weight.detach().float().reshape(conv.out_channels, 9).t().contiguous()      # [9][C]
         P = {"stem": (self.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(16, 27).contiguous(),) + self._affine(self.bn1)}
         for si, st in enumerate(self.blocks):
@@ -376,6 +383,7 @@ class SmirkEncoder(nn.Module):
         outputs = {}
         if not img.is_cuda:
             raise L.SmirkHipError("smirk_amd runs on the MI355X HIP device only: got a CPU tensor (no CPU fallback exists)")
+        L.raise_if_range_tripped("smirk_amd.SmirkEncoder.forward")          # an overflow of the split-fp16 format in an EARLIER call is reported now (no sync)
         # SMIRK_ENCODER_SERIAL: profiling aid (reference order on one stream).  Training uses the three streams as well unless SMIRK_ENCODER_TRAIN_SERIAL is
         # set: autograd runs every backward node on the stream its forward ran on and orders the streams itself, so the backbones' backward passes
         # interleave exactly like their forward passes (their ~1000 launches per step are small and latency-bound one after the other).

@@ -151,6 +151,12 @@ class SmirkGenerator(nn.Module):
                              up.bias.detach().float().contiguous())
             block(getattr(self, f"decoder{lvl}"), f"dec{lvl}")
         if split:
+            # weights (and folded BatchNorm coefficients) the fp16 `hi` half cannot carry: refused when the image is built, with the layer's name
+            for k, v in P.items():
+                big = max(float(t.abs().max()) if t is not None and t.numel() else 0.0 for t in v)
+                if not big < 65504.0:
+                    raise L.SmirkHipError(f"SmirkGenerator layer '{k}': |weight| or folded BatchNorm coefficient = {big:.4g} does not fit the split-fp16 format "
+                                          "(|x| < 65504); use precision = 'f32' for this checkpoint")
             P = {k: (_split16(v[0]),) + tuple(v[1:]) for k, v in P.items()}
         P["final"] = (self.conv.weight.detach().float().reshape(self.out_channels, self.features).contiguous(), None,
                       self.conv.bias.detach().float().contiguous())
@@ -185,6 +191,7 @@ class SmirkGenerator(nn.Module):
     def _run(self, a, b, taps=None):
         """One call of smirk_generator_forward: cat(a, b) NCHW -> sigmoid image.  Every layer is enqueued from C on the current stream; the
         activations live in a per-stream workspace owned by this module."""
+        L.raise_if_range_tripped("smirk_amd.SmirkGenerator.forward")      # an overflow of the split-fp16 format in an EARLIER call is reported now (no sync)
         if self.training:
             # train mode (smirk_trainer.py:349-355 calls self.train() before every step): batch-statistics BatchNorm with running-stat updates and a
             # real backward pass — one autograd.Function over the whole network (smirk_amd/generator_train.py, csrc/train.hip)

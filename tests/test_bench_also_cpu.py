@@ -27,12 +27,15 @@ def test_also_specs_name_every_baseline_config_and_failures_are_contained():
 
 
 def test_child_command_line_is_one_a_builder_can_run_by_hand():
-    """every child argv parses with bench.py's own parser and switches off what only the parent does (also, counter passes, CPU baseline)"""
+    """every child argv parses with bench.py's own parser and switches off what only the parent does (also, counter passes); every entry has a CPU baseline
+    of its own (a bounded sample timed by the child) or names the line that holds the same CPU path"""
     sys.path.insert(0, REPO)
     import bench
-    for name, argv, steps, warmup in bench.ALSO_SPECS:
-        a = bench.parse_args(argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", "0", "--no-also"])
-        assert a.no_also and a.traffic == "off" and a.cpu_faces == 0 and a.steps == steps and a.gpus == 1, name
+    for name, argv, steps, warmup, cpu_faces in bench.ALSO_SPECS:
+        a = bench.parse_args(argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off", "--cpu-faces", str(cpu_faces), "--cpu-passes", "3", "--no-also"])
+        assert a.no_also and a.traffic == "off" and a.cpu_faces == cpu_faces and a.cpu_passes == 3 and a.steps == steps and a.gpus == 1, name
+        assert cpu_faces > 0 or name in bench.ALSO_CPU_SAME_AS, name
+    assert {n for n, *_ in bench.ALSO_SPECS if _[-1] > 0} == {"flame512", "infer256", "train64_f16x3"}
 
 
 def test_rocprofv3_per_launch_figure_is_quoted_only_for_the_same_kernel_sources(tmp_path, monkeypatch):

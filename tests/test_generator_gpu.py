@@ -99,8 +99,49 @@ def test_f16x3_range_check_flags_a_badly_scaled_checkpoint(monkeypatch):
         m.encoder3.enc3norm2.weight.mul_(3e5)                      # blow one block's activations past 65504
         with pytest.raises(SmirkHipError, match="enc3"):
             m(x)
+        import smirk_amd
+        with pytest.raises(SmirkHipError, match="split-fp16"):     # the ALWAYS-ON flag (no environment switch) saw the same overflow; reading it clears it
+            smirk_amd.check_numerics()
         m.precision = "f32"                                        # the exact-fp32 mode carries them (no audit needed)
         assert torch.isfinite(m(x)).all()
+        smirk_amd.check_numerics()                                 # ... and does not trip the flag
+
+
+def test_split_fp16_overflow_raises_instead_of_returning_nan_pixels():
+    """the only silent-wrong-answer mode of the library.  A deliberately 1e4-scaled state_dict (every conv weight x 1e4: each weight still fits
+    the format, the activations of the second layer do not) is loaded with NO environment switch set: the forward that overflows returns (nothing synchronises on
+    the hot path), and the NEXT call — or smirk_amd.check_numerics() — raises SmirkHipError; the flag is sticky until read, healthy weights do not trip it, and a
+    NaN in the input image is reported the same way."""
+    import smirk_amd
+    from smirk_amd import SmirkGenerator, SmirkHipError
+    good = G.synth_state_dict()
+    bad = {k: (v * 1e4 if (k.endswith("conv1.weight") or k.endswith("conv2.weight")) else v) for k, v in good.items()}
+    m = SmirkGenerator(in_channels=6, out_channels=3, init_features=32, res_blocks=5)
+    m.load_state_dict(bad)
+    m = m.cuda().eval()
+    x = A.synth_generator_input(2, seed=5).cuda()
+    with torch.no_grad():
+        y = m(x)                                                   # overflows on the device; returns without synchronising
+        torch.cuda.synchronize()
+        assert not bool(((y > 1e-3) & (y < 1 - 1e-3)).all())       # (the pixels ARE garbage: saturated / NaN — exactly what must not pass silently)
+        with pytest.raises(SmirkHipError, match="split-fp16"):
+            m(x)                                                   # "raise on the next call"
+        y = m(x)                                                   # the raise cleared the flag: this call runs, and trips it again
+        with pytest.raises(SmirkHipError, match="split-fp16"):
+            smirk_amd.check_numerics()                             # explicit form: synchronises, then reads the flag
+        m.load_state_dict(good)
+        y = m(x)
+        smirk_amd.check_numerics()                                 # healthy weights: silent
+        assert torch.isfinite(y).all()
+        xn = x.clone(); xn[1, 2, 100, 100] = float("nan")
+        m(xn)
+        with pytest.raises(SmirkHipError, match="split-fp16"):
+            smirk_amd.check_numerics()
+        # a weight the format cannot carry at all is refused when the weight image is built, naming the layer
+        worse = dict(good); worse["encoder2.enc2conv1.weight"] = good["encoder2.enc2conv1.weight"] * 1e7
+        m.load_state_dict(worse)
+        with pytest.raises(SmirkHipError, match="enc2"):
+            m(x)
 
 
 @pytest.mark.parametrize("cin,feat,res", [(10, 32, 2), (16, 16, 1), (12, 24, 1)])

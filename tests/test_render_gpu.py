@@ -95,6 +95,41 @@ def test_render_depth_culling_is_bit_exact_on_adversarial_vertex_sets(rend, sand
         assert (packed >= 0).mean() > 0.05, kind                                # the case really draws something
 
 
+def test_render_full_head_mesh_takes_the_unsorted_fallback_and_matches_the_oracle(sandbox):
+    """advisor r05: a mesh beyond SORT_N = 4096 faces skips the in-LDS depth sort (raster_face_setup, mesh order, zlow = 0, four per-wave bin lists of Ff / 4 entries).
+    Renderer(render_full_head=True) is exactly that mesh in the reference (renderer.py:50-74: all 9976 faces of head_template.obj) — every shipped test rendered
+    the 3408-face sub-mesh, so the branch never ran against the oracle.  pix_to_face / barycentrics / z-buffer bit-exact, pixels within PIX_TOL."""
+    from smirk_amd import Renderer
+
+    class FullHeadRef(RendererRef):
+        def __init__(self, root):
+            super().__init__(root)
+            _, _, faces, _ = A.parse_obj(os.path.join(root, "assets", "head_template.obj"))
+            self.final_mask, self.faces = np.arange(int(faces.max()) + 1), faces
+
+    cwd = os.getcwd(); os.chdir(sandbox)
+    try:
+        full = Renderer(render_full_head=True).cuda()
+    finally:
+        os.chdir(cwd)
+    B = 2
+    p = A.synth_flame_params(B, seed=23)
+    p["shape_params"] *= 0.4
+    verts, cam = FlameRef(sandbox).forward(p)["vertices"], A.synth_cam(B, seed=23)
+    ref = FullHeadRef(sandbox).forward(verts, cam)
+    out, aux = _gpu(full, verts, cam)
+    Ff = 9976
+    assert full.faces.shape[1] == Ff > 4096
+    p2f = ref["_aux"]["pix_to_face"].astype(np.int64)
+    packed = np.where(p2f >= 0, p2f + (np.arange(B, dtype=np.int64) * Ff)[:, None, None], -1)
+    assert np.array_equal(aux["pix_to_face"], packed)
+    assert np.array_equal(aux["bary"], ref["_aux"]["bary"]) and np.array_equal(aux["zbuf"], ref["_aux"]["zbuf"])
+    assert np.abs(out["rendered_img"] - ref["rendered_img"]).max() < PIX_TOL
+    assert np.array_equal(out["transformed_vertices"][..., :2], ref["transformed_vertices"][..., :2])
+    assert np.array_equal(out["transformed_vertices"][..., 2], ref["transformed_vertices"][..., 2] + np.float32(10))     # renderer.py:141 quirk (in-place z += 10)
+    assert (packed >= 0).mean() > 0.1
+
+
 def test_render_edge_cases(rend, sandbox):
     """mesh partly / wholly off-screen, tiny scale (sub-pixel triangles), huge scale (few big triangles)."""
     fr = FlameRef(sandbox)

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 OUT_TOL = 2e-5          # generator sigmoid output, abs (same bound as tests/test_generator_gpu.py)
 PIX_TOL = 2e-6          # rendered pixels (same bound as tests/test_render_gpu.py)
-from enc_tolerances import VS_FP32 as ENC_TOL      # 2 x the measured max |HIP - fp32 oracle| over these very batches (tests/enc_tolerances.py)
+from enc_tolerances import VS_FP32 as ENC_TOL      # 4 x the measured max |HIP - fp32 oracle| over these very batches (tests/enc_tolerances.py)
 
 
 @pytest.fixture(scope="module")
