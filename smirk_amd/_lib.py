@@ -139,6 +139,9 @@ _SIGS = {
     "smirk_backbone_workspace_bytes": (_sz, [C.POINTER(SmirkBackboneWeights), _i, _i, _i]),
     "smirk_backbone_forward": (_i, [C.POINTER(SmirkBackboneWeights), _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
+    "smirk_conv_stats_rows_max": (_sz, [C.POINTER(SmirkConvDesc)]),
+    "smirk_conv_igemm_stats_split16": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, C.POINTER(C.c_int), _i, _p]),
+    "smirk_bn_train_forward_partials_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_eval_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _p, _p, _i, C.c_float, _p, _p, _p, _p]),

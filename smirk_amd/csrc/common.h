@@ -59,6 +59,32 @@ __device__ __forceinline__ void smirk_range_audit4(const float* v) {
     const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     if (__builtin_expect(!(m < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
 }
+// The hot epilogues (MFMA convolution kernels, the encoder's fused blocks) do not branch per group: a branch in the middle of an unrolled epilogue keeps the scheduler from
+// overlapping one item's LDS reads with the previous item's stores (measured, round 6: +3-7 % on the 224^2 / 112^2 generator kernels, +47 % on the register-bound
+// mbconv_image instantiation).  They keep ONE running maximum per lane (v_max3_f32: 4 instructions per 8-channel group, one VGPR) and test it once, before the kernel ends.
+struct SmirkRangeAcc {
+    float m;
+    __device__ __forceinline__ SmirkRangeAcc() : m(0.f) {}
+    __device__ __forceinline__ void see8(const float* v) {
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])); m = fmaxf(fmaxf(m, fabsf(v[2])), fabsf(v[3]));
+        m = fmaxf(fmaxf(m, fabsf(v[4])), fabsf(v[5])); m = fmaxf(fmaxf(m, fabsf(v[6])), fabsf(v[7]));
+    }
+    __device__ __forceinline__ void see1(float v) { m = fmaxf(m, fabsf(v)); }
+    __device__ __forceinline__ void commit() const { if (__builtin_expect(!(m < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip(); }
+};
+// The same audit for kernels that sit AT their VGPR budget (enc1_fused, conv3x3_ring<2,pool>, mbconv_image<7,4>: one more live VGPR is a spill): the per-group maximum
+// is compared at once and the wave's verdict is OR-ed into a scalar register pair — 4 v_max3 + v_cmp + s_or_b64 per group, no VGPR held, no branch.
+struct SmirkRangeAccS {
+    unsigned long long bad;
+    __device__ __forceinline__ SmirkRangeAccS() : bad(0ull) {}
+    __device__ __forceinline__ void see8(const float* v) {
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                              fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+        bad |= __builtin_amdgcn_ballot_w64(!(m < SMIRK_F16_RANGE_LIMIT));
+    }
+    __device__ __forceinline__ void see1(float v) { bad |= __builtin_amdgcn_ballot_w64(!(fabsf(v) < SMIRK_F16_RANGE_LIMIT)); }
+    __device__ __forceinline__ void commit() const { if (__builtin_expect(bad != 0ull, 0)) smirk_range_trip(); }
+};
 __device__ __forceinline__ void smirk_range_audit1(float v) {                  // NaN-catching form (inputs from outside the library)
     if (__builtin_expect(!(fabsf(v) < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
 }
@@ -82,6 +108,25 @@ static inline int smirk_launch_status() {
 
 // row of a 32x32 MFMA accumulator register r (0..15) for this lane: (r&3) + 8*(r>>2) + 4*(lane>>5); column = lane&31
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- BatchNorm statistics from the MFMA accumulators (train mode) ----------------------------------------------------------------------------------------
+// In the 32x32 accumulator layout a lane holds ONE output channel (column lane & 31) and 16 pixel rows (mfma32_row): the per-channel sums of a wave's
+// [32 x 32] block are 16 adds + 16 FMAs on values the epilogue computes anyway (acc0 + acc1 * 2^-11) plus one exchange between lanes l and l + 32.
+// `valid` = number of rows of this block that exist (tiles ragged at the end of M repeat their last row: those must not be counted).
+__device__ __forceinline__ void stats_block(const float* x16, int lane, int valid, float& s1, float& s2) {
+    if (valid >= 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1 += x16[r]; s2 = fmaf(x16[r], x16[r], s2); }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = mfma32_row(r, lane) < valid ? x16[r] : 0.f;
+            s1 += x; s2 = fmaf(x, x, s2);
+        }
+    }
+}
+// sums of lanes l and l + 32 (the two row halves of a column), identical in both afterwards
+__device__ __forceinline__ float stats_pair(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // ---- launch profiler (smirk_profile_start / _stop in capi.hip) -------------------------------------------------------------------
 // Every launch of the library goes through SMIRK_LAUNCH: with the profiler armed the launch is bracketed by two hipEvents on its stream

@@ -72,7 +72,7 @@ __device__ __forceinline__ const float* psel(bool c, const float* p, const float
 enum { KW_GENERIC = 0, KW_FAST = 1, KW_FAST_KT = 2, KW_CMAJOR = 3, KW_LEAN = 4, KW_LEAN_CM = 5 };
 
 // one BM x BN output tile at (m0, n0); `smem` holds 2 pipeline stages of (BM + BN) x 32 dwords
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false, bool STATS = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const int m0, const int n0) {
     constexpr int NW = WGM * WGN, NT = 64 * NW;                 // waves / threads per workgroup (4 or 8 waves)
     constexpr int RP = NT / 8;                                  // operand rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
@@ -476,16 +476,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     if (SPLIT || (a.N % 8 == 0)) {                              // whole 8-channel groups: transpose through LDS, 2 x 16-byte stores per lane
         __syncthreads();                                          // every wave is done with As/Bs: reuse as transpose buffers
         float* ebuf = smem + wave * 32 * EPI_LD;
+        SmirkRangeAcc rng;                                        // split-fp16 range audit: running max of what this lane stores, tested once below
         constexpr int GPR = TN * 4;                               // 8-channel groups per buffer row
         constexpr int ITEMS = 32 * GPR / 64;
+        float st1[TN], st2[TN];                                   // STATS: this lane's column sums (sum z, sum z^2) over the wave's rows
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                float x16[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] =
-                        SPLIT ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] * (1.0f / 2048.0f) : acc[0][i][j][r];
+                for (int r = 0; r < 16; ++r) {
+                    x16[r] = SPLIT ? acc[0][i][j][r] + acc[NACC - 1][i][j][r] * (1.0f / 2048.0f) : acc[0][i][j][r];
+                    ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = x16[r];
+                }
+                if constexpr (STATS) stats_block(x16, lane, a.M - (m0 + (wm * TM + i) * 32), st1[j], st2[j]);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // per-wave buffer: no workgroup barrier, and no vmcnt drain (a
                                                                   // __syncthreads here would wait for the previous pass's output stores)
 #pragma unroll
@@ -533,7 +541,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                     }
                     if constexpr (SPLIT) {
                         half8 hi, lo;
-                        split8(v, hi, lo);
+                        split8(v, hi, lo, rng);
                         *(half8*)(a.out + o) = hi;
                         *(half8*)(a.out + o + 4) = lo;
                     } else {
@@ -543,6 +551,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if constexpr (SPLIT) rng.commit();
+        if constexpr (STATS) {                                    // partial row (tile, wave row): [N][2] floats, every (row, channel) written by exactly one lane
+            float* prow = a.stats + (size_t)((m0 / BM) * WGM + wm) * a.N * 2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t1 = stats_pair(st1[j]), t2 = stats_pair(st2[j]);
+                const int n = n0 + (wn * TN + j) * 32 + fr;
+                if (hb == 0 && n < a.N) { prow[n * 2] = t1; prow[n * 2 + 1] = t2; }
+            }
         }
     } else {
 #pragma unroll
@@ -574,13 +592,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem, const 
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false>
+template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false, bool STATS = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
     const int ntn = (a.N + BN - 1) / BN;
     const int logical = xcd_logical(blockIdx.x, gridDim.x);
     const int mt = logical / ntn, nt = logical % ntn;
-    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK, X1>(a, smem, mt * BM, nt * BN);
+    conv_tile<BM, BN, WGM, WGN, SPLIT, KWALK, X1, STATS>(a, smem, mt * BM, nt * BN);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SPLIT, int KWALK, bool X1 = false>
@@ -591,6 +609,12 @@ static void launch_igemm_kw(const ConvArgs& a, hipStream_t st) {
         snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d,%d,%d,%d,%s,%d>%s", BM, BN, WGM, WGN, SPLIT ? "true" : "false", KWALK, X1 ? "[f16x1]" : "");
         const double px = (double)a.d.B * a.d.H * a.d.W;
         smirk_prof_next(nm, 2.0 * a.M * a.N * a.K, 4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
+    }
+    if constexpr (SPLIT && (KWALK == KW_LEAN || KWALK == KW_LEAN_CM || KWALK == KW_FAST_KT)) {      // the walks the training step's layers take
+        if (a.stats) {
+            SMIRK_LAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK, X1, true>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
+            return;
+        }
     }
     SMIRK_LAUNCH((conv_igemm_kernel<BM, BN, WGM, WGN, SPLIT, KWALK, X1>), dim3(ntm * ntn), dim3(64 * WGM * WGN), 0, st, a);
 }
@@ -642,10 +666,11 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
 // conv_ring.hip: 16 x 16 patches, weights streamed through an LDS ring, two workgroups per CU (Cout = 64 at 112 x 112), optional fused 2 x 2 max-pool
 bool smirk_conv3x3_ring64_eligible(const SmirkConvDesc* d, bool has_residual);
 int smirk_conv3x3_ring64_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale, const float* shift, void* out,
-                                void* pooled, hipStream_t st);
+                                void* pooled, hipStream_t st, float* stats = nullptr, int* stats_rows = nullptr);
 
 static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                             const float* shift, const void* residual, void* out, void* stream, bool split, bool x1 = false);
+                             const float* shift, const void* residual, void* out, void* stream, bool split, bool x1 = false, float* stats = nullptr,
+                             int* stats_rows = nullptr);
 
 // The buffer-addressed operand DMA of the split-fp16 kernels (32-bit per-lane offsets, out-of-range rows as the zero padding) needs every
 // input tensor below 2 GiB.  A whole 1024-frame shard in one pass exceeds that on the 224^2 / 112^2 layers (6.6 / 3.3 GB): such a layer is
@@ -659,10 +684,12 @@ static int conv_batch_chunk(const SmirkConvDesc* d, bool split) {
 }
 
 static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                         const float* shift, const void* residual, void* out, void* stream, bool split, bool x1 = false) {
+                         const float* shift, const void* residual, void* out, void* stream, bool split, bool x1 = false, float* stats = nullptr,
+                         int* stats_rows = nullptr) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
+    if (stats_rows) *stats_rows = 0;                            // (a layer run as several batch chunks writes no statistics: the caller reduces the stored tensor)
     const int bc = (d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0) ? conv_batch_chunk(d, split) : d->B;
-    if (bc >= d->B) return conv_dispatch_one(d, in0, in1, w, scale, shift, residual, out, stream, split, x1);
+    if (bc >= d->B) return conv_dispatch_one(d, in0, in1, w, scale, shift, residual, out, stream, split, x1, stats, stats_rows);
     const size_t ipx = (size_t)d->H * d->W, opx = (size_t)d->Ho * d->Wo * (d->out_mode == SMIRK_OUT_CONVT2X2 ? 4 : 1);
     for (int b0 = 0; b0 < d->B; b0 += bc) {
         SmirkConvDesc dc = *d;
@@ -675,8 +702,9 @@ static int conv_dispatch(const SmirkConvDesc* d, const void* in0, const void* in
 }
 
 static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale,
-                             const float* shift, const void* residual, void* out, void* stream, bool split, bool x1) {
+                             const float* shift, const void* residual, void* out, void* stream, bool split, bool x1, float* stats, int* stats_rows) {
     if (!d || !in0 || !w || !out) return SMIRK_ERR_BAD_ARG;
+    if (stats_rows) *stats_rows = 0;
     if (x1 && !split) return SMIRK_ERR_BAD_ARG;
     const int cq = split ? 8 : 4;                               // channel granule: one 16-byte vector (fp32) / one hi+lo group
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->C0 <= 0 || d->C0 % cq || d->C1 % cq || d->C1 < 0 ||
@@ -698,6 +726,7 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
     if (M > (1ll << 30) || (long long)d->B * d->H * d->W > (1ll << 30)) return SMIRK_ERR_UNSUPPORTED;
     a.M = (int)M;
     a.ablate = 0;
+    a.stats = nullptr;
     a.psh = 0;
     if (d->KH == 3)                                             // only convs with a halo profit from patch ordering
         while (a.psh < 4 && d->Ho % (2 << a.psh) == 0 && d->Wo % (2 << a.psh) == 0) ++a.psh;
@@ -705,11 +734,28 @@ static int conv_dispatch_one(const SmirkConvDesc* d, const void* in0, const void
     static const bool no_patch = getenv("SMIRK_DISABLE_PATCH_KERNEL") != nullptr;   // A/B switch for tools/ and tests: neither the patch nor the ring kernels
     // F16X1 lives in conv_igemm_kernel only: the specialised kernels below issue the three-MFMA product unconditionally
     if (split && !x1 && !no_patch && smirk_conv3x3_ring64_eligible(d, residual != nullptr))         // conv_ring.hip: the 64-output-channel layers on large images
-        return smirk_conv3x3_ring64_launch(d, in0, in1, w, scale, shift, out, nullptr, st);
+        return smirk_conv3x3_ring64_launch(d, in0, in1, w, scale, shift, out, nullptr, st, stats, stats_rows);      // (they write statistics only for a raw epilogue)
     if (split && !x1 && !no_patch && smirk_conv3x3_patch_eligible(d, residual != nullptr))
         return smirk_conv3x3_patch_launch(d, in0, in1, w, scale, shift, out, st, nullptr, nullptr, nullptr, 0);
-    if (split && smirk_conv_halo_eligible(a)) return smirk_conv_halo_launch(a, st, x1);      // (the halo kernel has an X1 instantiation: conv_halo_x1_kernel)
+    // train mode: BatchNorm statistics of the RAW output from the accumulators (ConvArgs::stats), for the kernel families that carry the STATS epilogue
+    const bool want_stats = split && stats && stats_rows && d->out_mode == SMIRK_OUT_NHWC && !scale && !shift && !residual && d->act == SMIRK_ACT_NONE;
+    if (split && smirk_conv_halo_eligible(a)) {                    // (the halo kernel has an X1 instantiation: conv_halo_x1_kernel)
+        if (want_stats) { a.stats = stats; *stats_rows = ((a.M + 255) / 256) * 4; }            // 256-row tiles x 4 wave rows
+        return smirk_conv_halo_launch(a, st, x1);
+    }
     if (split && !x1 && smirk_conv_pp_eligible(a)) return smirk_conv_pp_launch(a, st);
+    if (want_stats) {
+        // the K walks launch_igemm picks for operands below 2 GiB (KW_LEAN / KW_LEAN_CM when
+        // every source has C % 32 == 0, KW_FAST_KT for 1x1 layers otherwise) carry the STATS epilogue; one partial row per (M tile, wave row)
+        const long long b0 = (long long)d->B * d->H * d->W * d->C0 * 4, b1 = (long long)d->B * d->H * d->W * d->C1 * 4, bw = (long long)a.N * a.K * 4;
+        const bool lean = (d->C0 % CV_BK == 0) && (d->C1 % CV_BK == 0) && b0 < (1ll << 31) && b1 < (1ll << 31) && bw < (1ll << 31);
+        const bool kt = !((d->C0 % CV_BK == 0) && (d->C1 % CV_BK == 0)) && d->KH * d->KW == 1;
+        if (lean || kt) {
+            const int BMt = a.N > 32 ? 128 : 256, WGMt = a.N > 32 ? 2 : 4;
+            a.stats = stats;
+            *stats_rows = ((a.M + BMt - 1) / BMt) * WGMt;
+        }
+    }
     if (split && x1) {                                           // F16X1: the same three tile shapes, one MFMA per block
         if (a.N > 64) launch_igemm<128, 128, 2, 2, true, true>(a, st);
         else if (a.N > 32) launch_igemm<128, 64, 2, 2, true, true>(a, st);
@@ -790,6 +836,22 @@ extern "C" int smirk_conv_igemm_f16x1(const SmirkConvDesc* d, const void* in0, c
                                       const float* scale, const float* shift, const void* residual, void* out,
                                       void* stream) {
     return conv_dispatch(d, in0, in1, w, scale, shift, residual, out, stream, true, true);
+}
+
+// Train mode: the raw convolution (no BatchNorm / activation / residual in the epilogue) that ALSO leaves the per-tile partial column sums (sum z, sum z^2) of its
+// output for the BatchNorm that follows (nn.BatchNorm2d in training mode after every convolution of smirk_generator.py:88-119 and of the timm backbones,
+// smirk_trainer.py:349-355): `stats` [smirk_conv_stats_rows_max(d)][Cout][2] floats; *rows = partial rows written, 0 when the kernel family that serves this shape
+// does not produce them (the caller then reduces the stored tensor: smirk_bn_train_forward_split16).  x1: one MFMA per product block (f16x1).
+extern "C" size_t smirk_conv_stats_rows_max(const SmirkConvDesc* d) {
+    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+    const size_t M = (size_t)d->B * d->Ho * d->Wo;
+    const size_t tiles = (M + 127) / 128 * 2 + 4;                // 128-row tiles x 2 wave rows (= 256-row tiles x 4)
+    return tiles > 4096 ? tiles : 4096;                          // the persistent patch / ring kernels: <= 3 workgroups per CU x 4 waves (one row each)
+}
+extern "C" int smirk_conv_igemm_stats_split16(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, void* out, float* stats, int* rows, int x1,
+                                              void* stream) {
+    if (!stats || !rows) return SMIRK_ERR_BAD_ARG;
+    return conv_dispatch(d, in0, in1, w, nullptr, nullptr, nullptr, out, stream, true, x1 != 0, stats, rows);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -13,6 +13,9 @@ struct ConvArgs {
     float* out;
     int M, N, K, Cin;
     int ablate;    // reserved for ablation experiments (unused in the shipped kernels)
+    float* stats;  // train mode (BatchNorm statistics from the accumulators): per-tile partial column sums [rows][N][2] = (sum z, sum z^2) in fp32, or nullptr.
+                   // Every kernel family that honours it states its row count through smirk_conv_stats_rows(); the fixed-order fp64 reduction over the rows is
+                   // bn_finalize_partials_kernel (train.hip)
     int psh;       // GEMM rows enumerate each image in (2^psh x 2^psh)-pixel patches (tile-major): a BM-row tile is then a compact 2-D
                    // patch whose 3x3 halo is ~1.3x its area instead of 3 full image rows — the im2col re-reads stay in L1/L2
 };
@@ -43,6 +46,17 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
         hi[q] = h.x; hi[q + 1] = h.y; lo[q] = l.x; lo[q + 1] = l.y;
     }
 }
+// the same split for the hot epilogues: the range audit goes into the lane's running maximum (SmirkRangeAcc, common.h), tested once per kernel
+template <typename RA>
+__device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo, RA& ra) {
+    ra.see8(v);
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        smirk_half2 h, l;
+        smirk_split2(v[q], v[q + 1], h, l);
+        hi[q] = h.x; hi[q + 1] = h.y; lo[q] = l.x; lo[q + 1] = l.y;
+    }
+}
 __device__ __forceinline__ float join1(_Float16 hi, _Float16 lo) { return (float)hi + (float)lo * (1.0f / 2048.0f); }
 
 
@@ -59,4 +73,3 @@ __device__ __forceinline__ int xcd_logical(int id, int nblk) {
     const int q = nblk >> 3, r = nblk & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
-

@@ -63,7 +63,7 @@ __device__ __forceinline__ int hs_b_off(int row, int stage, int piece) {
 //      pipe busy while the partner wakes up.  Nothing the barrier orders depends on the position of a wave's MFMAs (they only touch registers).
 // X1:  one fp16 MFMA per product block on the hi halves only (the training path's "f16x1" arithmetic, generator_train.TRAIN_ARITH): the lo fragments are neither
 //      read from LDS nor multiplied — 8 of the 24 MFMAs and 8 of the 16 fragment reads of a chunk remain.  Same K order as conv_igemm_kernel's X1 instantiation.
-template <int NPA, int EB, bool X1>
+template <int NPA, int EB, bool X1, bool STATS = false>
 __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
     constexpr int NL = 3;   // DMA instructions issued in the load phase: 1-3 measured equal, 0 (all among the MFMAs) 2-3 % slower (profiles/r03b_halo_nl_sweep.txt)
     extern __shared__ __attribute__((aligned(16))) float hs_smem[];
@@ -326,12 +326,20 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
 #endif
     // ---- epilogue: per-wave transpose through LDS, whole 8-channel groups, BN scale/shift + residual + ReLU, re-split ---------------------------
     HS_STAMP();
+    SmirkRangeAcc rng;                                              // split-fp16 range audit (common.h): one running max per lane, tested once after the stores
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};                 // STATS (train mode): this lane's column sums over the wave's 64 rows (conv_common.h stats_block)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            float x16[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ebuf[mfma32_row(r, lane) * HS_EPI_LD + j * 32 + fr] = X1 ? acc0[i][j][r] : acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+            for (int r = 0; r < 16; ++r) {
+                x16[r] = X1 ? acc0[i][j][r] : acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+                ebuf[mfma32_row(r, lane) * HS_EPI_LD + j * 32 + fr] = x16[r];
+            }
+            if constexpr (STATS) stats_block(x16, lane, a.M - (m0 + (wm * 2 + i) * 32), st1[j], st2[j]);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -359,12 +367,22 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
                     for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
                 half8 hi, lo;
-                split8(v, hi, lo);
+                split8(v, hi, lo, rng);
                 *(half8*)(a.out + o) = hi;
                 *(half8*)(a.out + o + 4) = lo;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    rng.commit();
+    if constexpr (STATS) {                                           // partial row (M tile, wave row 0..3): [N][2] floats, each (row, channel) written by one lane
+        float* prow = a.stats + (size_t)((m0 / HS_BM) * 4 + wm) * a.N * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float t1 = stats_pair(st1[j]), t2 = stats_pair(st2[j]);
+            const int n = n0 + wn * 64 + j * 32 + fr;
+            if ((lane >> 5) == 0) { prow[n * 2] = t1; prow[n * 2 + 1] = t2; }
+        }
     }
 #ifdef SMIRK_DEBUG_HOOKS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,6 +398,11 @@ template <int NPA, int EB>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(ConvArgs a) { conv_halo_body<NPA, EB, false>(a); }
 template <int NPA>
 __global__ __launch_bounds__(512, 2) void conv_halo_x1_kernel(ConvArgs a) { conv_halo_body<NPA, 0, true>(a); }
+// train mode: the same kernels leaving the BatchNorm partial sums of their raw output (ConvArgs::stats; one row per M tile and wave row)
+template <int NPA, int EB>
+__global__ __launch_bounds__(512, 2) void conv_halo_stats_kernel(ConvArgs a) { conv_halo_body<NPA, EB, false, true>(a); }
+template <int NPA>
+__global__ __launch_bounds__(512, 2) void conv_halo_x1_stats_kernel(ConvArgs a) { conv_halo_body<NPA, 0, true, true>(a); }
 
 static int hs_env_mode() {                                           // $SMIRK_IGEMM_HALO: "0" off; unset / anything else = every eligible geometry
     const char* env = getenv("SMIRK_IGEMM_HALO");                   // read per call: tests toggle it
@@ -411,8 +434,10 @@ template <int NPA, int EB, bool X1>
 static int hs_launch(const ConvArgs& a, hipStream_t st, size_t lds, int dev) {
     static bool attr_done[64] = {};                                  // hipFuncSetAttribute is per-device state (one process may drive several GPUs)
     const void* fn = X1 ? (const void*)conv_halo_x1_kernel<NPA> : (const void*)conv_halo_kernel<NPA, EB>;
+    const void* fns = X1 ? (const void*)conv_halo_x1_stats_kernel<NPA> : (const void*)conv_halo_stats_kernel<NPA, EB>;
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(fns, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return SMIRK_ERR_LAUNCH;
         attr_done[dev] = true;
     }
@@ -424,6 +449,11 @@ static int hs_launch(const ConvArgs& a, hipStream_t st, size_t lds, int dev) {
         else snprintf(nm, sizeof(nm), "conv_halo_kernel<%d,%d>[256x128,8w,halo]", NPA, EB);
         smirk_prof_next(nm, 2.0 * a.M * a.N * a.K,
                         4.0 * (px * a.Cin + (double)a.M * a.N + (double)a.N * a.K + (a.residual ? (double)a.M * a.N : 0.0)));
+    }
+    if (a.stats) {
+        if constexpr (X1) SMIRK_LAUNCH((conv_halo_x1_stats_kernel<NPA>), dim3(ntm * ntn), dim3(512), lds, st, a);
+        else SMIRK_LAUNCH((conv_halo_stats_kernel<NPA, EB>), dim3(ntm * ntn), dim3(512), lds, st, a);
+        return smirk_launch_status();
     }
     if constexpr (X1) SMIRK_LAUNCH((conv_halo_x1_kernel<NPA>), dim3(ntm * ntn), dim3(512), lds, st, a);
     else SMIRK_LAUNCH((conv_halo_kernel<NPA, EB>), dim3(ntm * ntn), dim3(512), lds, st, a);

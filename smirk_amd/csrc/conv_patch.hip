@@ -12,6 +12,7 @@
 // A concatenated input (decoder: up ++ skip) is two source tensors, one chunk sequence each.
 //
 // Bound: HBM (activation read 1.27x + write 1x) once the DMA is hidden; MFMA work is ~40 % of that time.
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -93,8 +94,9 @@ __device__ __forceinline__ void frag_ready(const half8& a0, const half8& a1, con
     asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
-__device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo) {
-    smirk_range_audit8(v);
+template <typename RA>
+__device__ __forceinline__ void split8p(const float* v, half8& hi, half8& lo, RA& rng) {
+    rng.see8(v);                                                   // split-fp16 range audit (common.h): running max, tested once per kernel
 #pragma unroll
     for (int q = 0; q < 8; q += 2) {
         smirk_half2 h, l;
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
     for (int q = 0; q < NQ; ++q) nq_w += ((q * 4 + swave) * 8 < PPIXT) ? 1 : 0;
     int st = 0, dbg_n = 0;
     bool first = true;
+    SmirkRangeAcc rng;
     if (GROUPS == 2 && !(item < nitem)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // idle group: still owes its weight share + the barrier
     while (item < nitem) {
         int b, oy0, ox0, cc;
@@ -359,8 +362,10 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+                    for (int r = 0; r < 16; ++r) {
+                        const float x = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+                        ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = x;
+                    }
                 wave_lds_fence();          // per-wave transpose buffer: LDS ops of one wave execute in order
 #pragma unroll
                 for (int it = 0; it < ITEMS; ++it) {
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
                         }
                     } else {
                         half8 hi, lo;
-                        split8p(v, hi, lo);
+                        split8p(v, hi, lo, rng);
                         float* o = a.out + (((size_t)b * a.H + oy) * a.W + ox) * COUT + g * 8;
                         *(half8*)o = hi;
                         *(half8*)(o + 4) = lo;
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256 * GROUPS, (NST == 1 && GROUPS == 1) ? 2 : 1) vo
         }
         item = nxt;
     }
+    rng.commit();
 }
 
 // Streamed-weights variant for Cout = 64 layers whose weight tensor does not fit in LDS next to the input stages (64->64, 128->64 at 112x112).
@@ -580,6 +586,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
     // Weight stage h holds half h of the current chunk; input stage (chunk_no & 1) holds the current chunk's halo patch.
     int chunk_no = 0;
     int p = blockIdx.x, cc = 0;
+    SmirkRangeAcc rng;
     if (p < a.npatch) { issue_input(p, 0, 0); issue_weights(0, 0, 0); }
     while (p < a.npatch) {
         int np = p, ncc = cc + 1;
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
                         for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                     }
                     half8 hi, lo;
-                    split8p(v, hi, lo);
+                    split8p(v, hi, lo, rng);
                     float* o = a.out + (((size_t)b * a.H + oy) * a.W + ox) * COUT + g * 8;
                     *(half8*)o = hi;
                     *(half8*)(o + 4) = lo;
@@ -644,6 +651,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch_stream_kernel(PatchArgs 
         ++chunk_no;
         p = np; cc = ncc;
     }
+    rng.commit();
 }
 
 // Can this layer run on the patch kernel?  (3x3, stride 1, zero pad 1, same size, H,W % 16 == 0, Cout 32/64, weights resident)
@@ -724,6 +732,8 @@ int smirk_conv3x3_patch_launch(const SmirkConvDesc* d, const void* in0, const vo
     const size_t lds = wbytes + (size_t)(one_stage ? 1 : 2) * PSTAGE * 4 + tail;
     const int cap = one_stage ? 512 : 256;
     const int grid = a.npatch < cap ? a.npatch : cap;
+    // (no statistics epilogue here: the <1,1,16,1> instantiation sits at 253 of its 256 VGPRs and the two running column sums would spill — round 6 tried; the three
+    // 32-channel 224 x 224 layers it serves in train mode keep the stand-alone statistics pass, which streams them at HBM rate)
     if (d->Cout == 32 && one_stage) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 1, 16, 1>), dim3(grid), dim3(256), lds, st, a);
     else if (d->Cout == 32) SMIRK_LAUNCH((conv3x3_patch_kernel<1, 2, 16, 1>), dim3(grid), dim3(256), lds, st, a);
     else SMIRK_LAUNCH((conv3x3_patch_kernel<2, 2, 16, 1>), dim3(grid), dim3(256), lds, st, a);

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     // ---- epilogue: per-wave transpose through LDS, whole 8-channel groups, BN scale/shift + residual + ReLU, re-split --------------------------
     float* ebuf = smem + wave * 32 * PP_EPI_LD;
     constexpr int GPR = 8, ITEMS = 32 * GPR / 64;                   // 8-channel groups per buffer row; items per lane
+    SmirkRangeAcc rng;                                              // split-fp16 range audit (common.h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -300,13 +301,14 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
                     for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
                 half8 hi, lo;
-                split8(v, hi, lo);
+                split8(v, hi, lo, rng);
                 *(half8*)(a.out + o) = hi;
                 *(half8*)(a.out + o + 4) = lo;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    rng.commit();
 }
 
 // Serves: split-fp16, 3x3, stride 1, NHWC out, both sources multiples of 32 channels and powers of two, N a multiple of 128, operands < 2 GiB.

@@ -34,6 +34,7 @@ struct RingArgs {
     float *out, *pool;
     int B, H, W, C0, C1;
     int nchunk, npatch, act;
+    float* stats;    // train mode: per (workgroup, wave) partial column sums [gridDim.x * 4][Cout][2] of the raw output (BatchNorm statistics), or nullptr
 };
 
 typedef __attribute__((address_space(3))) void* rg_lptr_t;
@@ -46,7 +47,7 @@ __device__ __forceinline__ void rg_frag_ready(const half8& a, const half8& b, co
 }
 
 // TN = output channels / 32 (1: the two-source 64 -> 32 layer at 224 x 224, 2: the 64-channel layers at 112 x 112); POOL: also write the 2 x 2 max-pool of the output
-template <int TN, bool POOL>
+template <int TN, bool POOL, bool STATS = false>
 __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(RingArgs a) {
     constexpr int COUT = 32 * TN, STAGE = COUT * 128, EPI_LD = COUT + 4, GPR = COUT / 8, ITEMS = 32 * GPR / 64;
     extern __shared__ __attribute__((aligned(16))) char rg_lds[];
@@ -120,6 +121,10 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
     dmaB(0, 1, 1);
     f32x16 acc0[2][TN], acc1[2][TN];
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float st1[TN], st2[TN];                                          // STATS: column sums of everything this wave computed (sum of per-patch sums: short fp32 chains)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+    SmirkRangeAccS rng;                                               // split-fp16 range audit (common.h): running max over every patch of this workgroup, tested once at the end
     for (; p < a.npatch; p += gridDim.x) {
         const int b = p / tiles_per_img, t = p - b * tiles_per_img, ty = t / tiles_x;
         const int oy0 = ty * RG_PT, ox0 = (t - ty * tiles_x) * RG_PT;
@@ -195,12 +200,21 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float* const ebuf = (float*)halo + wave * 32 * EPI_LD;
+        float pt1[TN], pt2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { pt1[j] = 0.f; pt2[j] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                float x16[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+                for (int r = 0; r < 16; ++r) {
+                    x16[r] = acc0[i][j][r] + acc1[i][j][r] * (1.0f / 2048.0f);
+                    ebuf[mfma32_row(r, lane) * EPI_LD + j * 32 + fr] = x16[r];
+                }
+                if constexpr (STATS) stats_block(x16, lane, 32, pt1[j], pt2[j]);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // per-wave transpose buffer: LDS operations of one wave execute in order
             const int oy = oy0 + 4 * wave + 2 * i;
             auto finish = [&](const float* src, float* v) {
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
                 float v[8];
                 finish(ebuf + row * EPI_LD + g * 8, v);
                 half8 hi, lo;
-                split8(v, hi, lo);
+                split8(v, hi, lo, rng);
                 float* o = a.out + (((size_t)b * H + oy + (row >> 4)) * W + ox0 + (row & 15)) * COUT + g * 8;
                 *(half8*)o = hi;
                 *(half8*)(o + 4) = lo;
@@ -242,13 +256,26 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
                     for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
                 }
                 half8 hi, lo;
-                split8(m, hi, lo);
+                split8(m, hi, lo, rng);
                 float* o = a.pool + (((size_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox0 >> 1) + pp) * COUT + g * 8;
                 *(half8*)o = hi;
                 *(half8*)(o + 4) = lo;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the buffer is rewritten by the next tile
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { st1[j] += pt1[j]; st2[j] += pt2[j]; }
+        }
+    }
+    rng.commit();
+    if constexpr (STATS) {
+        float* prow = a.stats + (size_t)(blockIdx.x * 4 + wave) * COUT * 2;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float t1 = stats_pair(st1[j]), t2 = stats_pair(st2[j]);
+            if (hb == 0) { prow[(j * 32 + fr) * 2] = t1; prow[(j * 32 + fr) * 2 + 1] = t2; }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the over-fetched weight pieces must have landed before the workgroup's LDS is released
@@ -267,7 +294,7 @@ bool smirk_conv3x3_ring64_eligible(const SmirkConvDesc* d, bool has_residual) {
 }
 
 int smirk_conv3x3_ring64_launch(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, const float* scale, const float* shift, void* out,
-                                void* pooled, hipStream_t st) {
+                                void* pooled, hipStream_t st, float* stats, int* stats_rows) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SMIRK_ERR_LAUNCH;
     static bool attr_done[64] = {};                                  // hipFuncSetAttribute is per-device state
@@ -275,7 +302,9 @@ int smirk_conv3x3_ring64_launch(const SmirkConvDesc* d, const void* in0, const v
     if (!attr_done[dev]) {
         if (hipFuncSetAttribute((const void*)conv3x3_ring_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES(64)) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_ring_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES(64)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_ring_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES(32)) != hipSuccess)
+            hipFuncSetAttribute((const void*)conv3x3_ring_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES(32)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_ring_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES(64)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_ring_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES(32)) != hipSuccess)
             return SMIRK_ERR_LAUNCH;
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -290,12 +319,17 @@ int smirk_conv3x3_ring64_launch(const SmirkConvDesc* d, const void* in0, const v
     a.npatch = d->B * (d->H / RG_PT) * (d->W / RG_PT);
     const int per_cu = d->Cout == 32 ? 3 : 2;                        // resident workgroups per CU (LDS)
     const int grid = a.npatch < per_cu * n_cu[dev] ? a.npatch : per_cu * n_cu[dev];
+    a.stats = nullptr;
+    if (stats && stats_rows && !pooled && !scale && !shift && d->act == SMIRK_ACT_NONE) { a.stats = stats; *stats_rows = grid * 4; }   // train mode: raw output + its column sums
     if (g_smirk_prof_on) {
         const double px = (double)d->B * d->H * d->W, K = 9.0 * (d->C0 + d->C1);
         smirk_prof_next(d->Cout == 32 ? "conv3x3_ring_kernel<1>[16x16 patch,ring]" : pooled ? "conv3x3_ring_kernel<2,pool>[16x16 patch,ring]" : "conv3x3_ring_kernel<2>[16x16 patch,ring]",
                         2.0 * px * d->Cout * K, px * (d->C0 + d->C1) * 4.0 + px * d->Cout * 4.0 * (pooled ? 1.25 : 1.0) + K * d->Cout * 4.0);
     }
-    if (d->Cout == 32) {
+    if (a.stats) {
+        if (d->Cout == 32) SMIRK_LAUNCH((conv3x3_ring_kernel<1, false, true>), dim3(grid), dim3(256), RG_LDS_BYTES(32), st, a);
+        else SMIRK_LAUNCH((conv3x3_ring_kernel<2, false, true>), dim3(grid), dim3(256), RG_LDS_BYTES(64), st, a);
+    } else if (d->Cout == 32) {
         if (pooled) return SMIRK_ERR_UNSUPPORTED;
         SMIRK_LAUNCH((conv3x3_ring_kernel<1, false>), dim3(grid), dim3(256), RG_LDS_BYTES(32), st, a);
     } else if (pooled) SMIRK_LAUNCH((conv3x3_ring_kernel<2, true>), dim3(grid), dim3(256), RG_LDS_BYTES(64), st, a);

@@ -88,8 +88,8 @@ __device__ __forceinline__ void e1_split2(float a, float b, unsigned& hi, unsign
 // stages).  Left to itself hipcc's scheduler, minimising register pressure next to the 255-VGPR matrix phases, emitted each value's nine dependent
 // operations back to back through ONE temporary register: ~9 cycles per VALU instruction, 4-6 k cycles per epilogue (tools/enc1_timeline.py).
 #define E1_FENCE() __builtin_amdgcn_sched_barrier(0)
-__device__ __forceinline__ void e1_split8(float (&y)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
-    smirk_range_audit8(y);
+__device__ __forceinline__ void e1_split8(float (&y)[8], unsigned (&hi)[4], unsigned (&lo)[4], SmirkRangeAccS& rng) {
+    rng.see8(y);                                                     // split-fp16 range audit (common.h): running max, tested once per kernel
     half2v h[4];
     float d[8];
 #pragma unroll
@@ -142,6 +142,7 @@ __device__ __forceinline__ void e1_frag_ready(const half8& a, const half8& b, co
 
 __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
     extern __shared__ __attribute__((aligned(16))) char e1_lds[];
+    SmirkRangeAccS rng;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave_all >> 2, wave = wave_all & 3;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                         for (int r = 0; r < 8; ++r) y[r] = inimg ? fmaxf(y[r], 0.f) : 0.f;
                         E1_FENCE();
                         unsigned hi[4], lo[4];
-                        e1_split8(y, hi, lo);
+                        e1_split8(y, hi, lo, rng);
                         if (own) {                                    // (a dump row for the other lanes serialises: same-address LDS writes are bank conflicts)
 #pragma unroll
                             for (int jj = 0; jj < 2; ++jj) {
@@ -442,8 +443,8 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                     for (int r = 0; r < 8; ++r) pz[r] = e1_max(pz[r], pw[r]);
                     E1_FENCE();
                     unsigned hi[4], lo[4], phi[4], plo[4];
-                    e1_split8(y, hi, lo);
-                    e1_split8(pz, phi, plo);
+                    e1_split8(y, hi, lo, rng);
+                    e1_split8(pz, phi, plo, rng);
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = hf * 2 + jj;
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
 #if E1_PHASE_OFFSET
     if (group == 0) __builtin_amdgcn_s_barrier();                    // both groups have executed the same number of barriers
 #endif
+    rng.commit();
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------------------

@@ -47,6 +47,7 @@ __device__ __forceinline__ int ds_off(int p, int quad) { return p * 16 + ((quad 
 
 template <int S>
 __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs a) {
+    SmirkRangeAcc rng;                                  // split-fp16 range audit (common.h)
     constexpr int TO = (S == 1) ? 16 : 8;               // output tile
     constexpr int TS = (TO - 1) * S + 3;                // stem-image halo tile (18 | 17)
     constexpr int TI = (TS - 1) * 2 + 3;                // image patch (37 | 35)
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
             }
             if (oy < a.Ho && ox < a.Wo) {
                 half8 hi, lo;
-                smirk_range_audit8(acc);
+                rng.see8(acc);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     _Float16 h, l;
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256, 3) void encoder_head_fused_kernel(EncHeadArgs 
             }
         }
     }
+    rng.commit();
 }
 
 /* 1 if smirk_encoder_head_fused_split16 serves this stem + first block (the caller keeps the unfused kernel sequence otherwise) */

@@ -50,6 +50,7 @@ __device__ __forceinline__ float mb_join(_Float16 hi, _Float16 lo) { return (flo
 // KS = Cin rounded up to 16, in 16-k MFMA steps (1..3: the fused path serves the blocks with Cin <= 48, i.e. everything down to 14x14)
 template <int S, bool EXP, int KS>
 __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
+    SmirkRangeAccS rng;                                 // split-fp16 range audit (common.h), scalar-register form (the <1,true,3> instantiation sits at its 168-VGPR budget)
     constexpr int THO = (S == 1) ? 8 : 4, TWO = 8;
     constexpr int HI = (THO - 1) * S + 3, WI = (TWO - 1) * S + 3, NH = HI * WI, MH = (NH + 31) / 32 * 32, MO = THO * TWO;
     // Es row stride (floats).  Phase 2 reads E with ds_read_b128, lane = (pixel p = tid >> 3, channel quad c4 = tid & 7); the hardware services a b128 read in the lane
@@ -256,16 +257,13 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
                     }
                 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                 half4 hi, lo;
-                float amax = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float v = fmaxf(acc[k] * s2[k] + b2[k], 0.f);
-                    amax = fmaxf(amax, v);
+                    const float v = fmaxf(acc[k] * s2[k] + b2[k], 0.f);       // (intermediate: an overflow here turns into inf / NaN in every output channel, audited below)
                     _Float16 h, l;
                     smirk_split1(v, h, l);
                     hi[k] = h; lo[k] = l;
                 }
-                if (__builtin_expect(!(amax < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
                 char* d = Ds + p * DSB + (c4 >> 1) * 32 + (c4 & 1) * 8;
                 *(half4*)d = hi;
                 *(half4*)(d + 16) = lo;
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
                 for (int k = 0; k < 8; ++k) v[k] += mb_join(hi[k], lo[k]);
             }
             half8 hi, lo;
-            smirk_range_audit8(v);
+            rng.see8(v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 _Float16 h, l;
@@ -342,6 +340,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_fused_kernel(MBArgs a) {
             *(half8*)(o + 16) = lo;
         }
     }
+    rng.commit();
 }
 
 static int mb_same_pad_lead(int n, int s) {

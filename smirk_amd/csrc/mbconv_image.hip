@@ -61,6 +61,7 @@ __device__ __forceinline__ int mbi_es(int gi, int c) { return gi * 32 + ((((c >>
 template <int KS, int NT, bool TILE = false, bool PADK = false>
 __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
     extern __shared__ __attribute__((aligned(16))) char mbi_smem[];
+    SmirkRangeAccS rng;                                 // split-fp16 range audit (common.h), scalar-register form: these instantiations sit at 226-256 VGPRs
     const int strideX = KS * 64 + 16;                   // Cin padded to 16 KS channels (zeros): odd multiple of 16 B
     char* Xs = mbi_smem;
     float* Es = (float*)(mbi_smem + a.off_es);
@@ -276,16 +277,15 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
                     }
                 const f32x4 sa = *(const f32x4*)(wc + 9 * 32 + c8), sb = *(const f32x4*)(wc + 9 * 32 + c8 + 4);
                 const f32x4 ba = *(const f32x4*)(wc + 10 * 32 + c8), bb = *(const f32x4*)(wc + 10 * 32 + c8 + 4);
-                float amax = 0.f;
+                // (no range audit on this INTERMEDIATE: a depthwise output beyond the fp16 range becomes inf here and reaches every output channel of the project
+                // GEMM as inf / NaN, which the audit of the block's output below reports — one audit site per kernel keeps the 226-256-VGPR instantiations spill-free)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float v = fmaxf(acc[q] * (q < 4 ? sa[q & 3] : sb[q & 3]) + (q < 4 ? ba[q & 3] : bb[q & 3]), 0.f);
-                    amax = fmaxf(amax, v);
                     _Float16 h, l;
                     smirk_split1(v, h, l);
                     dh[s][q] = h; dl[s][q] = l;
                 }
-                if (__builtin_expect(!(amax < SMIRK_F16_RANGE_LIMIT), 0)) smirk_range_trip();
             }
         }
         if (more) store_stage(c + 1);                   // the other Wp / Wc buffer: last read in chunk c-1, read next after two barriers
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
                             for (int k = 0; k < 8; ++k) v[k] += (float)hi[k] + (float)lo[k] * (1.0f / 2048.0f);
                         }
                         half8 hi, lo;
-                        smirk_range_audit8(v);
+                        rng.see8(v);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             _Float16 h, l;
@@ -366,6 +366,7 @@ __global__ __launch_bounds__(512, 2) void mbconv_image_kernel(MBIArgs a) {
             }
         }
     }
+    rng.commit();
 }
 
 struct MbiPlan { int ipw, rows, gsz, nb, off_es, off_wp, off_wc, off_gmap, tile, tiles_x, tiles_y, gpitch, rowsE, nbE, off_gmapE; size_t lds; };

@@ -39,6 +39,16 @@ inline unsigned row_blocks(size_t M, int RPB) {                             // b
     const size_t b = (M + RPB - 1) / RPB;
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
 }
+#define RED_BLOCKS 1024
+// blocks of a two-stage column reduction over a [M][C] split16 tensor: about one per 96 KB of tensor (each block must have enough rows to amortise its
+// reduction tail; few partials keep stage 2 one round trip long on the backbones' small tensors), at least 32, at most RED_BLOCKS (4 per CU on the U-Net's 400 MB tensors)
+inline unsigned red_blocks(size_t M, int C, int RPB) {
+    const size_t by_rows = (M + RPB - 1) / RPB, by_bytes = (M * (size_t)C * 4 + 98303) / 98304;
+    size_t nb = by_bytes < 32 ? 32 : by_bytes;
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb > by_rows) nb = by_rows;
+    return (unsigned)(nb ? nb : 1);
+}
 inline unsigned blocks_for(size_t items, unsigned cap) {
     const size_t g = (items + 255) / 256;
     return (unsigned)(g > cap ? cap : (g ? g : 1));
@@ -49,7 +59,6 @@ inline unsigned blocks_for(size_t items, unsigned cap) {
 //   MODE 0 (statistics)      f = z,            g = z*z
 //   MODE 1 (BN backward)     f = dyh,          g = dyh * xhat      with dyh = dy * [relu ? (xhat*gamma+beta > 0) : 1], xhat = (z-mean)*invstd
 // ---------------------------------------------------------------------------------------------------------------------------------
-#define RED_BLOCKS 512
 // DEV = true: device-coherent accesses (relaxed agent-scope atomics) for values that workgroups of ONE launch hand to each other.  Unused by the shipped
 // three-launch BatchNorm; the one-launch cooperative form that needed it was measured slower on this 8-XCD part (a grid barrier costs 15-20 us, a dependent
 // launch less: DESIGN.md 8.9, profiles/r02ai_bn_one_launch_experiment.txt) and was removed from the library in round 3 (git history: train.hip @ 9afbeda).
@@ -78,13 +87,17 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
 #pragma unroll
         for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
     }
-    // four rows per iteration: all their loads are issued before the first is consumed.  One row in flight per thread (8 waves per CU x 2 KB) is
-    // 16 KB per CU against ~2 us of HBM latency = the 2.1-2.6 TB/s this kernel measured; the accumulation order per thread stays row-ascending.
+    // U rows per iteration: all their loads are issued before the first is consumed.  One row in flight per thread (8 waves per CU x 2 KB) is
+    // 16 KB per CU against ~2 us of HBM latency = the 2.1-2.6 TB/s the first version measured; four rows and <= 512 blocks (two per CU) measured 1.7 TB/s
+    // on the generator's 400 MB tensors in round 5 — the chip wants ~10 MB in flight AND several workgroups per CU to cover each other's reduction tails, so the
+    // statistics pass now keeps 8 rows (256 B) per thread in flight and the dispatcher launches up to RED_BLOCKS = 1024 blocks; the accumulation order per
+    // thread stays row-ascending (bit-reproducible run to run).
+    constexpr int U = MODE == 0 ? 8 : 4;
     const size_t S = (size_t)gridDim.x * RPB;
-    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += 4 * S) {
-        float v[4][8], d[4][8];
+    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += U * S) {
+        float v[U][8], d[MODE == 1 ? U : 1][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const size_t r = r0 + u * S;
             if (r < M) {
                 load_group(z + (r * G + g) * 8, v[u]);
@@ -92,7 +105,7 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (r0 + u * S >= M) break;
             if (MODE == 0) {
 #pragma unroll
@@ -101,7 +114,7 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float xh = (v[u][q] - mu[q]) * is[q];
-                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
+                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[MODE == 1 ? u : 0][q];
                     s1[q] += (double)dh; s2[q] += (double)dh * (double)xh;
                 }
             }
@@ -173,6 +186,46 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
 }
 
+// The same finalisation from the fp32 per-tile partial sums that the convolution kernels leave behind (ConvArgs::stats: [P][C][2] = (sum z, sum z^2) per partial row):
+// one workgroup = 16 channels x 2 sums (one 128-byte segment of every partial row) x 32 row lanes; every thread adds its rows k*32 + rl in ascending order into
+// eight interleaved fp64 chains (eight loads in flight), the chains and then the 32 row lanes are combined in a fixed order -> bit-reproducible run to run.
+// P = M / 64 ... M / 128 partial rows: 98-196 for the 14 x 14 layers (one round trip), 12544 for a 112 x 112 layer at 64 frames (49 round trips of L2 hits).
+__global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(const float* __restrict__ part, int P, int C, double n, float eps, float momentum,
+                                                                    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
+                                                                    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt) {
+    __shared__ double red[32][33];
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+    const int t = threadIdx.x & 31, rl = threadIdx.x >> 5, c0 = blockIdx.x * 16;
+    const bool on = c0 * 2 + t < C * 2;
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        const float* p = part + (size_t)c0 * 2 + t;
+        int k = rl;
+        for (; k + 7 * 32 < P; k += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 32 * u) * C * 2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += (double)v[u];
+        }
+        for (int u = 0; k < P; k += 32, ++u) s[u] += (double)p[(size_t)k * C * 2];
+    }
+    red[rl][t] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (rl != 0 || !on) return;
+    double a = 0.0;
+    for (int k = 0; k < 32; ++k) a += red[k][t];
+    const double b = __shfl_xor(a, 1, 64);                               // lanes (2c, 2c + 1) hold (sum z, sum z^2) of channel c0 + c
+    if (t & 1) return;
+    const int c = c0 + (t >> 1);
+    const double m = a / n;
+    double v = b / n - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m; var[c] = (float)v; invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
+}
+
 // MODE 1 / plain column sums: out1[c] = S1, out2[c] = S2 (as fp32)
 __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ part, int nblocks, int C, float* __restrict__ out1, float* __restrict__ out2) {
     __shared__ double red[16][16][2];
@@ -195,23 +248,34 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ z, size_
     float mu[8], is[8], ga[8], be[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { mu[q] = ld_x<DEV>(mean + g * 8 + q); is[q] = ld_x<DEV>(invstd + g * 8 + q); ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
-    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
-        const size_t i = r * G + g;
-        float v[8];
-        load_group(z + i * 8, v);
+    // four rows per iteration, every load issued before the first result is stored (one row in flight per thread measured 3.2 TB/s on the generator's tensors)
+    const size_t S = (size_t)gridDim.x * RPB;
+    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; r0 < M; r0 += 4 * S) {
+        float v[4][8], rr[4][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mu[q]) * is[q] * ga[q] + be[q];
-        if (residual) {
-            float rr[8];
-            load_group(residual + i * 8, rr);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += rr[q];
+        for (int u = 0; u < 4; ++u) {
+            const size_t r = r0 + u * S;
+            if (r < M) {
+                load_group(z + (r * G + g) * 8, v[u]);
+                if (residual) load_group(residual + (r * G + g) * 8, rr[u]);
+            }
         }
-        if (relu) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        for (int u = 0; u < 4; ++u) {
+            const size_t r = r0 + u * S;
+            if (r >= M) break;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[u][q] = (v[u][q] - mu[q]) * is[q] * ga[q] + be[q];
+            if (residual) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[u][q] += rr[u][q];
+            }
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[u][q] = fmaxf(v[u][q], 0.f);
+            }
+            store_group(y + (r * G + g) * 8, v[u]);
         }
-        store_group(y + i * 8, v);
     }
 }
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
@@ -235,18 +299,26 @@ __device__ __forceinline__ void bn_backward_apply_body(const float* __restrict__
         const int c = g * 8 + q;
         mu[q] = mean[c]; is[q] = invstd[c]; ga[q] = gamma[c]; be[q] = beta[c]; s1[q] = ld_x<DEV>(sum_dy + c) * inv_n; s2[q] = ld_x<DEV>(sum_dy_xhat + c) * inv_n;
     }
-    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
-        const size_t i = r * G + g;
-        float v[8], d[8];
-        load_group(z + i * 8, v);
-        load_group(dy + i * 8, d);
+    const size_t S = (size_t)gridDim.x * RPB;
+    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; r0 < M; r0 += 2 * S) {               // two rows = four 32-byte loads in flight per thread
+        float v[2][8], d[2][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float xh = (v[q] - mu[q]) * is[q];
-            const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[q];
-            v[q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
+        for (int u = 0; u < 2; ++u) {
+            const size_t r = r0 + u * S;
+            if (r < M) { load_group(z + (r * G + g) * 8, v[u]); load_group(dy + (r * G + g) * 8, d[u]); }
         }
-        store_group(dz + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t r = r0 + u * S;
+            if (r >= M) break;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float xh = (v[u][q] - mu[q]) * is[q];
+                const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
+                v[u][q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
+            }
+            store_group(dz + (r * G + g) * 8, v[u]);
+        }
     }
 }
 __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
@@ -1059,12 +1131,29 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
+    const unsigned nb = red_blocks(M, C, RPB);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
                  (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
                  save_invstd, running_mean, running_var, num_batches_tracked);
+    smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
+    SMIRK_LAUNCH(bn_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, M, G, (const float*)save_mean,
+                 (const float*)save_invstd, gamma, beta, (const float*)residual, relu, (float*)y);
+    return smirk_launch_status();
+}
+
+/* The same BatchNorm forward when the convolution that produced z already left the per-tile partial sums of z (smirk_conv_igemm_stats_split16, rows > 0):
+ * finalise from the P partial rows (fixed-order fp64) + apply — the statistics pass over z and one launch are gone. */
+extern "C" int smirk_bn_train_forward_partials_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
+                                                       float eps, float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                                       float* save_mean, float* save_var, float* save_invstd, void* y, const float* partials, int P, void* stream) {
+    if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !partials || P <= 0 || M == 0 || C <= 0 || C % 8 || C / 8 > 256)
+        return SMIRK_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 8, RPB = 256 / G;
+    SMIRK_LAUNCH(bn_finalize_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, P, C, (double)M, eps, momentum, save_mean, save_var, save_invstd,
+                 running_mean, running_var, num_batches_tracked);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
     SMIRK_LAUNCH(bn_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, M, G, (const float*)save_mean,
                  (const float*)save_invstd, gamma, beta, (const float*)residual, relu, (float*)y);
@@ -1079,7 +1168,7 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
+    const unsigned nb = red_blocks(M, C, RPB);
     SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
@@ -1126,7 +1215,7 @@ extern "C" int smirk_colsum_split16(const void* x, size_t M, int C, float* sums,
     if (ws_bytes < smirk_train_reduce_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    const unsigned nb = (unsigned)((M + RPB - 1) / RPB > RED_BLOCKS ? RED_BLOCKS : (M + RPB - 1) / RPB);
+    const unsigned nb = red_blocks(M, C, RPB);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)x, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
                  (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, sums, (float*)nullptr);

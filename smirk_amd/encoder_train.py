@@ -29,6 +29,11 @@ class _EncOps(_Ops):
         B, H, W, _ = x.shape
         return self.conv(x, None, w_split, B, H, W, cout, k=1, residual=residual)
 
+    def pointwise_stats(self, x, w_split, cout):
+        """1x1 convolution followed by a BatchNorm: -> (z, partial sums of z or None) (generator_train._Ops.conv_stats)"""
+        B, H, W, _ = x.shape
+        return self.conv_stats(x, None, w_split, B, H, W, cout, k=1)
+
     def depthwise(self, x, w9c, stride):
         B, H, W, C = x.shape
         if C not in self.ones:
@@ -105,24 +110,24 @@ class BackboneTrainFunction(torch.autograd.Function):
                     z1 = ops.depthwise(x, wdw, blk.stride)
                     y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
                     wf, wt = ops.pack(blk.conv_pw.weight)
-                    z2 = ops.pointwise(y1, wf, blk.conv_pw.out_channels)
-                    out, m2, i2 = ops.bn_forward(z2, blk.bn2, False, residual=x if blk.skip else None)
+                    z2, s2 = ops.pointwise_stats(y1, wf, blk.conv_pw.out_channels)
+                    out, m2, i2 = ops.bn_forward(z2, blk.bn2, False, residual=x if blk.skip else None, stats=s2)
                     tape.append(("ds", blk, (x, z1, m1, i1, y1, z2, m2, i2, wdw, wt)))
                 elif blk.kind == "ir":
                     wf1, wt1 = ops.pack(blk.conv_pw.weight)
-                    z1 = ops.pointwise(x, wf1, blk.conv_pw.out_channels)
-                    y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
+                    z1, s1 = ops.pointwise_stats(x, wf1, blk.conv_pw.out_channels)
+                    y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True, stats=s1)
                     wdw = _dw(blk.conv_dw)
                     z2 = ops.depthwise(y1, wdw, blk.stride)
                     y2, m2, i2 = ops.bn_forward(z2, blk.bn2, True)
                     wf3, wt3 = ops.pack(blk.conv_pwl.weight)
-                    z3 = ops.pointwise(y2, wf3, blk.conv_pwl.out_channels)
-                    out, m3, i3 = ops.bn_forward(z3, blk.bn3, False, residual=x if blk.skip else None)
+                    z3, s3 = ops.pointwise_stats(y2, wf3, blk.conv_pwl.out_channels)
+                    out, m3, i3 = ops.bn_forward(z3, blk.bn3, False, residual=x if blk.skip else None, stats=s3)
                     tape.append(("ir", blk, (x, z1, m1, i1, y1, z2, m2, i2, y2, z3, m3, i3, wt1, wdw, wt3)))
                 else:
                     wf, wt = ops.pack(blk.conv.weight)
-                    z1 = ops.pointwise(x, wf, blk.conv.out_channels)
-                    out, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
+                    z1, s1 = ops.pointwise_stats(x, wf, blk.conv.out_channels)
+                    out, m1, i1 = ops.bn_forward(z1, blk.bn1, True, stats=s1)
                     tape.append(("cn", blk, (x, z1, m1, i1, wt)))
                 x = out
         Bf, hf, wf, Cf = x.shape

@@ -71,9 +71,31 @@ class _Ops:
             raise L.SmirkHipError(f"train_arith must be one of {TRAIN_ARITH}, got {arith!r}")
         self.x1 = arith == "f16x1"                       # one MFMA per product block (hi halves only): BASELINE config 5's 16-bit class
         self.plan = None
+        import os
+        self.fuse_stats = not os.environ.get("SMIRK_BN_STATS_UNFUSED")       # A/B switch for tests: BatchNorm statistics by a pass over the stored tensor
         self.rm_saved = {}                                # eval-mode BatchNorm: id(bn) -> running_mean as the forward saw it
         self.red_ws = torch.empty(self.lib.smirk_train_reduce_workspace_bytes(1024), dtype=torch.uint8, device=device)
         self.wg_ws = None
+
+    def conv_stats(self, x0, x1, w, B, H, W, cout, k=3, reflect=False):
+        """the raw convolution whose BatchNorm follows: -> (z, (partials, rows) or None).  The kernel leaves per-tile partial sums (sum z, sum z^2) of its output
+        from the MFMA accumulators where the kernel family serving the shape can (smirk_conv_igemm_stats_split16); `None` = reduce the stored tensor instead."""
+        if self.eval_bn or not self.fuse_stats:
+            return self.conv(x0, x1, w, B, H, W, cout, k=k, reflect=reflect), None
+        d = L.SmirkConvDesc()
+        d.B, d.H, d.W = B, H, W
+        d.C0, d.C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+        d.Cout, d.KH, d.KW, d.stride = cout, k, k, 1
+        d.pad_t = d.pad_l = (k - 1) // 2
+        d.Ho, d.Wo = H, W
+        d.pad_mode = L.PAD_REFLECT if reflect else L.PAD_ZERO
+        d.act, d.out_mode = L.ACT_NONE, L.OUT_NHWC
+        out = torch.empty((B, H, W, cout), device=self.dev)
+        part = torch.empty((self.lib.smirk_conv_stats_rows_max(d), cout, 2), device=self.dev)
+        rows = L.C.c_int(0)
+        P = L.ptr
+        L.check(self.lib.smirk_conv_igemm_stats_split16(d, P(x0), P(x1, allow_none=True), P(w), P(out), P(part), L.C.byref(rows), int(self.x1), self.st))
+        return out, ((part, rows.value) if rows.value > 0 else None)
 
     def conv(self, x0, x1, w, B, H, W, cout, k=3, reflect=False, pad=None, out_hw=None, convt=False, shift=None, residual=None):
         d = L.SmirkConvDesc()
@@ -111,7 +133,7 @@ class _Ops:
         L.check(self.lib.smirk_pack_conv_weights_split16(L.ptr(w), cout, ctot, cin_off, cin, k, cp, L.ptr(f, allow_none=True), L.ptr(d, allow_none=True), self.st))
         return f, d
 
-    def bn_forward(self, z, bn, relu, residual=None):
+    def bn_forward(self, z, bn, relu, residual=None, stats=None):
         C = z.shape[-1]
         M = z.numel() // C
         mean, var, inv = (torch.empty(C, device=self.dev) for _ in range(3))
@@ -136,6 +158,13 @@ class _Ops:
             raise L.SmirkHipError("BatchNorm2d(momentum=None) (cumulative average) cannot be captured into a HIP graph: its factor 1 / num_batches_tracked is a host "
                                   "scalar read with a device synchronisation and would be frozen into the replay; use a numeric momentum (the reference does)")
         mom = float(bn.momentum) if bn.momentum is not None else (1.0 / max(int(bn.num_batches_tracked), 1) if track else 0.0)
+        if stats is not None:                            # the producing convolution left the partial sums of z: finalise from them, no pass over z
+            part, rows = stats
+            L.check(self.lib.smirk_bn_train_forward_partials_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
+                                                                     float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),
+                                                                     P(bn.running_var if track else None, allow_none=True), P(nbt, torch.int64, allow_none=True),
+                                                                     P(mean), P(var), P(inv), P(y), P(part), int(rows), self.st))
+            return y, mean, inv
         L.check(self.lib.smirk_bn_train_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
                                                         float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),
                                                         P(bn.running_var if track else None, allow_none=True), P(nbt, torch.int64, allow_none=True), P(mean), P(var),
@@ -301,11 +330,11 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 wf1, _ = ops.pack(c1.weight, dgrad=False)
                 wd1a = ops.pack(c1.weight, 0, c0, fwd=False)[1]
                 wd1b = ops.pack(c1.weight, c0, x1.shape[-1], fwd=False)[1]
-            z1 = ops.conv(x0, x1, wf1, B, h, w, c)
-            y1, mu1, iv1 = ops.bn_forward(z1, n1, True)
+            z1, st1 = ops.conv_stats(x0, x1, wf1, B, h, w, c)
+            y1, mu1, iv1 = ops.bn_forward(z1, n1, True, stats=st1)
             wf2, wd2 = ops.pack(c2.weight)
-            z2 = ops.conv(y1, None, wf2, B, h, w, c)
-            y2, mu2, iv2 = ops.bn_forward(z2, n2, True)
+            z2, st2 = ops.conv_stats(y1, None, wf2, B, h, w, c)
+            y2, mu2, iv2 = ops.bn_forward(z2, n2, True, stats=st2)
             tape.append(("block", (c1, n1, c2, n2), (x0, x1, z1, mu1, iv1, y1, z2, mu2, iv2, wd1a, wd1b, wd2), (h, w, c)))
             return y2
 
@@ -324,11 +353,11 @@ class GeneratorTrainFunction(torch.autograd.Function):
         for rb in module.resnet_blocks:
             cb = rb.conv_block
             wfa, wda = ops.pack(cb[1].weight)
-            za = ops.conv(b, None, wfa, B, h16, w16, c16, reflect=True)
-            ya, mua, iva = ops.bn_forward(za, cb[2], True)
+            za, sta = ops.conv_stats(b, None, wfa, B, h16, w16, c16, reflect=True)
+            ya, mua, iva = ops.bn_forward(za, cb[2], True, stats=sta)
             wfb, wdb = ops.pack(cb[5].weight)
-            zb = ops.conv(ya, None, wfb, B, h16, w16, c16, reflect=True)
-            nb, mub, ivb = ops.bn_forward(zb, cb[6], False, residual=b)
+            zb, stb = ops.conv_stats(ya, None, wfb, B, h16, w16, c16, reflect=True)
+            nb, mub, ivb = ops.bn_forward(zb, cb[6], False, residual=b, stats=stb)
             tape.append(("res", (cb[1], cb[2], cb[5], cb[6]), (b, za, mua, iva, ya, zb, mub, ivb, wda, wdb), (h16, w16, c16)))
             b = nb
         d = b

@@ -151,12 +151,13 @@ class SmirkGenerator(nn.Module):
                              up.bias.detach().float().contiguous())
             block(getattr(self, f"decoder{lvl}"), f"dec{lvl}")
         if split:
-            # weights (and folded BatchNorm coefficients) the fp16 `hi` half cannot carry: refused when the image is built, with the layer's name
+            # a WEIGHT the fp16 `hi` half cannot carry is refused when the image is built, with the layer's name (the folded BatchNorm scale / shift stay fp32:
+            # what they do to the activations is the device-side audit's business)
             for k, v in P.items():
-                big = max(float(t.abs().max()) if t is not None and t.numel() else 0.0 for t in v)
+                big = float(v[0].abs().max()) if v[0].numel() else 0.0
                 if not big < 65504.0:
-                    raise L.SmirkHipError(f"SmirkGenerator layer '{k}': |weight| or folded BatchNorm coefficient = {big:.4g} does not fit the split-fp16 format "
-                                          "(|x| < 65504); use precision = 'f32' for this checkpoint")
+                    raise L.SmirkHipError(f"SmirkGenerator layer '{k}': |weight| = {big:.4g} does not fit the split-fp16 format (|x| < 65504); "
+                                          "use precision = 'f32' for this checkpoint")
             P = {k: (_split16(v[0]),) + tuple(v[1:]) for k, v in P.items()}
         P["final"] = (self.conv.weight.detach().float().reshape(self.out_channels, self.features).contiguous(), None,
                       self.conv.bias.detach().float().contiguous())

@@ -144,6 +144,10 @@ def test_split16_roundtrip_is_fp32_class():
     normal = (mag >= 2.0 ** -10) & (mag < 6e4)          # hi is a normal fp16 => 22 significand bits survive
     assert (err[normal] / mag[normal]).max().item() < 2.0 ** -21
     assert err[mag < 2.0 ** -10].max().item() < 2.0 ** -31   # below that the error is bounded in absolute terms (fp16 subnormal grid / 2^11)
+    # the sample's tail (|x| up to ~1e5) is beyond what `hi` can carry: the conversion kernel says so through the library's always-on range flag
+    torch.cuda.synchronize()
+    assert bool((mag >= 65520).any()) == bool(L.lib().smirk_range_flag_peek())
+    L.lib().smirk_range_flag_clear()
 
 
 # ---- enc1_fused.hip: conv(8 -> 32) + BN + ReLU -> conv(32 -> 32) + BN + ReLU -> e1 + maxpool(e1) in one launch (smirk_generator.py:52-53) ----------------

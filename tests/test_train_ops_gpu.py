@@ -478,3 +478,52 @@ def test_weight_gradient_in_parameter_layout_equals_the_packed_one(arith):
     out = torch.full((64, 32, 2, 2), float("nan"), device="cuda")
     ops.wgrad_param(xin, s2d, B, H, W, 64, 128, 1, out, layout=2)
     assert torch.equal(out, ref)
+
+
+# ---- round 6: BatchNorm statistics from the producing convolution's accumulators -------------------------------------------------------
+@pytest.mark.parametrize("arith", ["f16x3", "f16x1"])
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [(2, 14, 14, 16, 64, 1), (3, 7, 7, 72, 24, 1), (1, 28, 28, 40, 120, 1), (5, 7, 7, 160, 960, 1), (2, 9, 11, 112, 672, 1),
+                                              (1, 56, 56, 128, 128, 3), (2, 28, 28, 256, 256, 3), (3, 10, 6, 64, 64, 3), (1, 17, 13, 32, 32, 3),
+                                              (1, 112, 112, 64, 64, 3), (2, 64, 64, 64, 32, 3), (5, 14, 14, 512, 512, 3)])
+def test_conv_epilogue_statistics_equal_the_sums_of_the_stored_output(B, H, W, cin, cout, k, arith):
+    """smirk_conv_igemm_stats_split16: the raw convolution's output is bit-identical to the plain entry's, and the per-tile partial sums it leaves (sum z, sum z^2 from the
+    fp32 accumulators, one row per M tile and wave row; ragged last tiles, Cout not a multiple of the 128-wide tile, K not a multiple of 32; the implicit-GEMM walks,
+    the halo kernel's 256-row tiles and the persistent ring kernels' per-workgroup rows) add up to the column sums of the stored tensor.  Then the BatchNorm that consumes them (finalise from partials + apply) equals the BatchNorm that reduces the stored tensor."""
+    from smirk_amd import _lib as L
+    T, ops = _ops()
+    ops = T._Ops(torch.device("cuda"), arith=arith)
+    g = _gen(cin * 7 + cout + k)
+    xs, _ = _act(torch.randn(B, H, W, cin, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.5 / (cin * k * k) ** 0.5)
+    wf = T._pack_fwd(w.cuda()) if k == 3 else T._split16(w.reshape(cout, cin).cuda())
+    z_plain = ops.conv(xs, None, wf, B, H, W, cout, k=k)
+    z, st = ops.conv_stats(xs, None, wf, B, H, W, cout, k=k)
+    assert torch.equal(z, z_plain)
+    assert st is not None, "the implicit-GEMM kernels serve these shapes and carry the statistics epilogue"
+    part, rows = st
+    M = B * H * W
+    assert 0 < rows <= L.lib().smirk_conv_stats_rows_max(_desc(B, H, W, cin, cout, k)) == part.shape[0]
+    p = part[:rows].double().sum(0).cpu()                                         # [cout][2]
+    zv = _val(z).permute(0, 2, 3, 1).reshape(M, cout)
+    s1, s2 = zv.sum(0), (zv * zv).sum(0)
+    # the accumulators hold z BEFORE it is rounded into the split format (2^-22 relative per element) and are summed in fp32 per tile (<= 256 rows)
+    assert (p[:, 0] - s1).abs().max().item() <= 2e-6 * zv.abs().sum(0).max().item() + 1e-6
+    assert (p[:, 1] - s2).abs().max().item() <= 4e-6 * s2.max().item() + 1e-9
+    bn = torch.nn.BatchNorm2d(cout).cuda().train()
+    bn2 = torch.nn.BatchNorm2d(cout).cuda().train()
+    y_a, mu_a, iv_a = ops.bn_forward(z, bn, True, stats=st)
+    y_b, mu_b, iv_b = ops.bn_forward(z, bn2, True)
+    assert (mu_a - mu_b).abs().max().item() <= 1e-6 * max(1.0, mu_b.abs().max().item())
+    assert ((iv_a - iv_b).abs() / iv_b).max().item() <= 5e-6
+    assert _rel(_val(y_a), _val(y_b)) < 1e-5
+    assert torch.allclose(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def _desc(B, H, W, cin, cout, k):
+    from smirk_amd import _lib as L
+    d = L.SmirkConvDesc()
+    d.B, d.H, d.W, d.C0, d.C1, d.Cout, d.KH, d.KW, d.stride = B, H, W, cin, 0, cout, k, k, 1
+    d.pad_t = d.pad_l = (k - 1) // 2
+    d.Ho, d.Wo, d.pad_mode, d.act, d.out_mode = H, W, L.PAD_ZERO, L.ACT_NONE, L.OUT_NHWC
+    return d
