@@ -459,6 +459,15 @@ int smirk_conv_wgrad_set_mode(int mode);
 int smirk_pack_conv_weights_split16(const float* w, int Cout, int cin_total, int cin_off, int Cin, int KH, int cin_pad, void* fwd, void* dgrad, void* stream);
 /* The same for EVERY weight of a network in one launch: `jobs_device` is a device array of njobs descriptors (arguments of the entry above; fwd / dgrad may be
  * NULL per job), `start` = the job's first index in the flattened list of 8-channel output vectors, total_vectors = the list's length. */
+/* job kinds beyond the nn.Conv2d weights (KH = 1 / 3), selected by a negative KH — every weight re-layout of a training step in the ONE launch:
+ *   SMIRK_PACK_DEPTHWISE  w = depthwise weight [C][1][3][3] (Cout = C) -> fwd = fp32 [9][C] (smirk_dwconv3x3_split16's image); C * 9 / 8 work items
+ *   SMIRK_PACK_STEM       w = stem weight [Cout][3][3][3] -> fwd = fp32 [Cout][(ky,kx,c)] (smirk_stem_conv_s2_raw_split16's image); Cout * 27 work items
+ *   SMIRK_PACK_CONVT2X2   w = nn.ConvTranspose2d(Cin_t, Cout_t, 2, 2) weight [Cin_t][Cout_t][2][2] with Cout = Cin_t and Cin = Cout_t in the descriptor ->
+ *                         fwd = split16 [(dydx, co)][ci] (the forward 1x1 form of smirk_generator.py:30-44's upconv), dgrad = split16 [ci][(dydx, co)];
+ *                         4 * Cin_t * Cout_t / 8 work items each (fwd first; either may be NULL) */
+#define SMIRK_PACK_DEPTHWISE (-3)
+#define SMIRK_PACK_STEM (-27)
+#define SMIRK_PACK_CONVT2X2 (-2)
 typedef struct SmirkPackJob {
     const float* w;
     void* fwd;
@@ -502,6 +511,8 @@ int smirk_stem_conv_s2_dgrad_split16(const void* dz, const float* w, float* dimg
 int smirk_dwconv3x3_dgrad_split16(const void* dz, const float* w, const void* add, void* dx, int B, int H, int W, int C, int stride, void* stream);
 size_t smirk_dwconv3x3_wgrad_workspace_bytes(int C);
 int smirk_dwconv3x3_wgrad_split16(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
+/* the same gradient written in the parameter's own layout [C][1][3][3] (conv_dw.weight of the timm blocks: no transpose-copy between backward and Adam) */
+int smirk_dwconv3x3_wgrad_param_split16(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
 /* F.adaptive_avg_pool2d(features, 1) + nn.Linear backward (smirk_encoder.py:18-22): dout [B][N], w [N][C], pooled [B][C] (the forward's workspace) ->
  * dw [N][C], db [N] (both or neither), dfeat split16 [B][HW][C] (nullable) */
 int smirk_gap_linear_backward_split16(const float* dout, const float* w, const float* pooled, float* dw, float* db, void* dfeat, int B, int HW, int C, int N,

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsmirk_hip.so")
 LIB_PATH = os.environ.get("SMIRK_HIP_LIBRARY", LIB_PATH)      # tuning aid: A/B a differently-built libsmirk_hip.so in one gpurun
 ABI_VERSION = 11
+PACK_DEPTHWISE, PACK_STEM, PACK_CONVT2X2 = -3, -27, -2          # SmirkPackJob.KH markers (include/smirk_hip.h SMIRK_PACK_*)
 SMIRK_OK, SMIRK_ERR_BAD_ARG, SMIRK_ERR_WORKSPACE, SMIRK_ERR_LAUNCH, SMIRK_ERR_UNSUPPORTED = 0, -1, -2, -3, -4      # include/smirk_hip.h
 
 _p = C.c_void_p
@@ -166,6 +167,7 @@ _SIGS = {
     "smirk_dwconv3x3_dgrad_split16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "smirk_dwconv3x3_wgrad_workspace_bytes": (_sz, [_i]),
     "smirk_dwconv3x3_wgrad_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "smirk_dwconv3x3_wgrad_param_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_gap_linear_backward_split16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "smirk_profile_start": (_i, []),
     "smirk_profile_stop": (_i, [C.POINTER(SmirkProfileRecord), _i]),

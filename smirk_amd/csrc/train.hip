@@ -39,15 +39,14 @@ inline unsigned row_blocks(size_t M, int RPB) {                             // b
     const size_t b = (M + RPB - 1) / RPB;
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
 }
-#define RED_BLOCKS 1024
-// blocks of a two-stage column reduction over a [M][C] split16 tensor: about one per 96 KB of tensor (each block must have enough rows to amortise its
-// reduction tail; few partials keep stage 2 one round trip long on the backbones' small tensors), at least 32, at most RED_BLOCKS (4 per CU on the U-Net's 400 MB tensors)
+#define RED_BLOCKS 512
+// blocks of a two-stage column reduction over a [M][C] split16 tensor.  (Round 6 tried up to 1024 blocks chosen by tensor size, eight rows in flight per thread in the
+// statistics pass and four in the apply kernels: bn_apply 3.96 -> 4.40 ms per training step, the backward sums 3.26 -> 3.69 ms, the statistics pass unchanged — the
+// extra registers cost more occupancy than the loads in flight bought — and went back to this.)
 inline unsigned red_blocks(size_t M, int C, int RPB) {
-    const size_t by_rows = (M + RPB - 1) / RPB, by_bytes = (M * (size_t)C * 4 + 98303) / 98304;
-    size_t nb = by_bytes < 32 ? 32 : by_bytes;
-    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-    if (nb > by_rows) nb = by_rows;
-    return (unsigned)(nb ? nb : 1);
+    (void)C;
+    const size_t by_rows = (M + RPB - 1) / RPB;
+    return (unsigned)(by_rows > RED_BLOCKS ? RED_BLOCKS : (by_rows ? by_rows : 1));
 }
 inline unsigned blocks_for(size_t items, unsigned cap) {
     const size_t g = (items + 255) / 256;
@@ -87,17 +86,13 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
 #pragma unroll
         for (int q = 0; q < 8; ++q) { mu[q] = mean[g * 8 + q]; is[q] = invstd[g * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
     }
-    // U rows per iteration: all their loads are issued before the first is consumed.  One row in flight per thread (8 waves per CU x 2 KB) is
-    // 16 KB per CU against ~2 us of HBM latency = the 2.1-2.6 TB/s the first version measured; four rows and <= 512 blocks (two per CU) measured 1.7 TB/s
-    // on the generator's 400 MB tensors in round 5 — the chip wants ~10 MB in flight AND several workgroups per CU to cover each other's reduction tails, so the
-    // statistics pass now keeps 8 rows (256 B) per thread in flight and the dispatcher launches up to RED_BLOCKS = 1024 blocks; the accumulation order per
-    // thread stays row-ascending (bit-reproducible run to run).
-    constexpr int U = MODE == 0 ? 8 : 4;
+    // four rows per iteration: all their loads are issued before the first is consumed.  One row in flight per thread (8 waves per CU x 2 KB) is
+    // 16 KB per CU against ~2 us of HBM latency = the 2.1-2.6 TB/s this kernel measured; the accumulation order per thread stays row-ascending.
     const size_t S = (size_t)gridDim.x * RPB;
-    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += U * S) {
-        float v[U][8], d[MODE == 1 ? U : 1][8];
+    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += 4 * S) {
+        float v[4][8], d[4][8];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const size_t r = r0 + u * S;
             if (r < M) {
                 load_group(z + (r * G + g) * 8, v[u]);
@@ -105,7 +100,7 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < 4; ++u) {
             if (r0 + u * S >= M) break;
             if (MODE == 0) {
 #pragma unroll
@@ -114,7 +109,7 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float xh = (v[u][q] - mu[q]) * is[q];
-                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[MODE == 1 ? u : 0][q];
+                    const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
                     s1[q] += (double)dh; s2[q] += (double)dh * (double)xh;
                 }
             }
@@ -248,34 +243,23 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ z, size_
     float mu[8], is[8], ga[8], be[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { mu[q] = ld_x<DEV>(mean + g * 8 + q); is[q] = ld_x<DEV>(invstd + g * 8 + q); ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
-    // four rows per iteration, every load issued before the first result is stored (one row in flight per thread measured 3.2 TB/s on the generator's tensors)
-    const size_t S = (size_t)gridDim.x * RPB;
-    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; r0 < M; r0 += 4 * S) {
-        float v[4][8], rr[4][8];
+    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
+        const size_t i = r * G + g;
+        float v[8];
+        load_group(z + i * 8, v);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t r = r0 + u * S;
-            if (r < M) {
-                load_group(z + (r * G + g) * 8, v[u]);
-                if (residual) load_group(residual + (r * G + g) * 8, rr[u]);
-            }
+        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mu[q]) * is[q] * ga[q] + be[q];
+        if (residual) {
+            float rr[8];
+            load_group(residual + i * 8, rr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += rr[q];
         }
+        if (relu) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t r = r0 + u * S;
-            if (r >= M) break;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[u][q] = (v[u][q] - mu[q]) * is[q] * ga[q] + be[q];
-            if (residual) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[u][q] += rr[u][q];
-            }
-            if (relu) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[u][q] = fmaxf(v[u][q], 0.f);
-            }
-            store_group(y + (r * G + g) * 8, v[u]);
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
         }
+        store_group(y + i * 8, v);
     }
 }
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, size_t M, int G, const float* __restrict__ mean,
@@ -299,26 +283,18 @@ __device__ __forceinline__ void bn_backward_apply_body(const float* __restrict__
         const int c = g * 8 + q;
         mu[q] = mean[c]; is[q] = invstd[c]; ga[q] = gamma[c]; be[q] = beta[c]; s1[q] = ld_x<DEV>(sum_dy + c) * inv_n; s2[q] = ld_x<DEV>(sum_dy_xhat + c) * inv_n;
     }
-    const size_t S = (size_t)gridDim.x * RPB;
-    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; r0 < M; r0 += 2 * S) {               // two rows = four 32-byte loads in flight per thread
-        float v[2][8], d[2][8];
+    for (size_t r = (size_t)blockIdx.x * RPB + rl; r < M; r += (size_t)gridDim.x * RPB) {
+        const size_t i = r * G + g;
+        float v[8], d[8];
+        load_group(z + i * 8, v);
+        load_group(dy + i * 8, d);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const size_t r = r0 + u * S;
-            if (r < M) { load_group(z + (r * G + g) * 8, v[u]); load_group(dy + (r * G + g) * 8, d[u]); }
+        for (int q = 0; q < 8; ++q) {
+            const float xh = (v[q] - mu[q]) * is[q];
+            const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[q];
+            v[q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const size_t r = r0 + u * S;
-            if (r >= M) break;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float xh = (v[u][q] - mu[q]) * is[q];
-                const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[u][q];
-                v[u][q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
-            }
-            store_group(dz + (r * G + g) * 8, v[u]);
-        }
+        store_group(dz + i * 8, v);
     }
 }
 __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G, float inv_n,
@@ -1082,6 +1058,36 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const Smir
         }
         const SmirkPackJob J = jobs[lo];
         const size_t li = (size_t)(i - J.start);
+        if (J.KH == SMIRK_PACK_DEPTHWISE) {                        // nn.Conv2d(C, C, 3, groups=C) weight [C][1][3][3] -> fp32 [9][C] (the depthwise kernels' tap-major image)
+            const int k = (int)((li * 8) / (size_t)J.Cout), c0 = (int)((li * 8) % (size_t)J.Cout);
+            float* o = (float*)J.fwd + li * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = J.w[(size_t)(c0 + q) * 9 + k];
+            continue;
+        }
+        if (J.KH == SMIRK_PACK_STEM) {                             // Conv2d(3, Cout, 3) weight [Cout][3][3][3] -> fp32 [Cout][(ky,kx,c)]; one item = one float (27 per row)
+            const int co = (int)(li / 27), k = (int)(li % 27), c = k % 3, t = k / 3;
+            ((float*)J.fwd)[li] = J.w[((size_t)co * 3 + c) * 9 + t];
+            continue;
+        }
+        if (J.KH == SMIRK_PACK_CONVT2X2) {                         // nn.ConvTranspose2d(Cin_t, Cout_t, 2, 2) weight [Cin_t][Cout_t][2][2]; Cout = Cin_t, Cin = Cout_t here
+            const int Ci = J.Cout, Co = J.Cin;                     //   fwd   [(dydx, co)][ci]  split16: the forward 1x1 form (out_mode CONVT2X2)
+            const size_t nfw = J.fwd ? (size_t)4 * Co * Ci / 8 : 0; //   dgrad [ci][(dydx, co)]  split16: its data gradient (a 1x1 convolution over the space-to-depth gradient)
+            float v[8];
+            if (li < nfw) {
+                const int row = (int)((li * 8) / (size_t)Ci), ci0 = (int)((li * 8) % (size_t)Ci), t = row / Co, co = row % Co;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = J.w[((size_t)(ci0 + q) * Co + co) * 4 + t];
+                store_group((float*)J.fwd + li * 8, v);
+            } else {
+                const size_t j = li - nfw;
+                const int ci = (int)((j * 8) / (size_t)(4 * Co)), col = (int)((j * 8) % (size_t)(4 * Co)), t = col / Co, co0 = col % Co;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = J.w[((size_t)ci * Co + co0 + q) * 4 + t];
+                store_group((float*)J.dgrad + j * 8, v);
+            }
+            continue;
+        }
         const int T = J.KH * J.KH;
         const size_t nf = J.fwd ? (size_t)J.Cout * T * J.cin_pad / 8 : 0;
         float v[8];

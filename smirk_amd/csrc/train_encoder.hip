@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_stage1(const float* __restrict__
         }
     }
 }
-__global__ __launch_bounds__(256) void dw_wgrad_stage2(const double* __restrict__ part, int nblocks, int C, float* __restrict__ dw /*[9][C]*/) {
+template <bool PARAM>     // PARAM: write nn.Conv2d's depthwise parameter layout [C][1][3][3] instead of the kernels' tap-major [9][C]
+__global__ __launch_bounds__(256) void dw_wgrad_stage2(const double* __restrict__ part, int nblocks, int C, float* __restrict__ dw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * 9) return;
     const int c = i / 9, k = i % 9;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_stage2(const double* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[j] += part[((size_t)(b + j) * C + c) * 9 + k];
     for (; b < nblocks; ++b) s[0] += part[((size_t)b * C + c) * 9 + k];
-    dw[k * C + c] = (float)((s[0] + s[1]) + (s[2] + s[3]));
+    dw[PARAM ? i : k * C + c] = (float)((s[0] + s[1]) + (s[2] + s[3]));
 }
 
 // ---- stem: Conv2d(3, Cout, 3, stride 2, TF 'SAME'), image NCHW fp32, output gradient split16 [B][Ho][Wo][Cout] ----------------------------
@@ -300,8 +301,8 @@ extern "C" int smirk_dwconv3x3_dgrad_split16(const void* dz, const float* w, con
 
 extern "C" size_t smirk_dwconv3x3_wgrad_workspace_bytes(int C) { return (size_t)DW_RED_BLOCKS * (size_t)C * 9 * sizeof(double); }
 
-extern "C" int smirk_dwconv3x3_wgrad_split16(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes,
-                                             void* stream) {
+static int dw_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream,
+                         bool param_layout) {
     if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C / 8 > 256 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_dwconv3x3_wgrad_workspace_bytes(C)) return SMIRK_ERR_WORKSPACE;
     const int G = C / 8, RPB = 256 / G;
@@ -310,8 +311,18 @@ extern "C" int smirk_dwconv3x3_wgrad_split16(const void* dz, const void* x, floa
     hipStream_t st = (hipStream_t)stream;
     smirk_prof_next(nullptr, 18.0 * (double)M * C, 4.0 * ((double)B * H * W * C + (double)M * C));
     SMIRK_LAUNCH(dw_wgrad_stage1, dim3(nb), dim3(256), 0, st, (const float*)dz, (const float*)x, B, H, W, G, stride, (double*)ws);
-    SMIRK_LAUNCH(dw_wgrad_stage2, dim3((C * 9 + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, dw);
+    if (param_layout) SMIRK_LAUNCH(dw_wgrad_stage2<true>, dim3((C * 9 + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, dw);
+    else SMIRK_LAUNCH(dw_wgrad_stage2<false>, dim3((C * 9 + 255) / 256), dim3(256), 0, st, (const double*)ws, (int)nb, C, dw);
     return smirk_launch_status();
+}
+extern "C" int smirk_dwconv3x3_wgrad_split16(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes,
+                                             void* stream) {
+    return dw_wgrad_impl(dz, x, dw, B, H, W, C, stride, ws, ws_bytes, stream, false);
+}
+/* the same gradient written in the parameter's layout [C][1][3][3] (what autograd hands the optimiser for the depthwise `conv_dw.weight.grad`) */
+extern "C" int smirk_dwconv3x3_wgrad_param_split16(const void* dz, const void* x, float* dw, int B, int H, int W, int C, int stride, void* ws, size_t ws_bytes,
+                                                   void* stream) {
+    return dw_wgrad_impl(dz, x, dw, B, H, W, C, stride, ws, ws_bytes, stream, true);
 }
 
 extern "C" size_t smirk_stem_conv_s2_wgrad_workspace_bytes(int Cout) { return (size_t)STEM_BLOCKS * 27 * (size_t)Cout * sizeof(float); }

@@ -110,8 +110,13 @@ def graph_cycle_modules(generator, encoder, generator_input, encoder_input, grad
     enc = _CycleEncoder(encoder, grad_keys)
     gen = _CycleGenerator(generator)
     enc.train(); gen.train()
-    gi = generator_input.detach().clone()
-    ei = encoder_input.detach().clone().requires_grad_(True)
+    # The samples only fix shapes, dtype and device: make_graphed_callables runs its warm-up and capture passes ON them (they become the static input buffers that
+    # every replay overwrites).  Constant samples (callers pass zeros) make every BatchNorm's batch variance exactly 0, i.e. invstd = 1 / sqrt(eps) = 316, and the
+    # warm-up BACKWARD multiplies the gradient by that factor in each of the generator's 28 BatchNorm layers: inf / NaN gradients that the split-fp16 range flag
+    # (include/smirk_hip.h smirk_range_flag_peek) rightly reports at the next forward.  Warm up on uniform noise instead (seeded: the capture is reproducible).
+    g = torch.Generator(device=generator_input.device).manual_seed(20240)
+    gi = torch.rand(generator_input.shape, generator=g, device=generator_input.device, dtype=generator_input.dtype)
+    ei = torch.rand(encoder_input.shape, generator=g, device=encoder_input.device, dtype=encoder_input.dtype).requires_grad_(True)
     # Capture on ONE stream: eager training runs the three backbones on three side streams, but a capture that forks to pre-existing side streams and joins
     # them back (with one backbone's backward pruned) made hipStreamEndCapture segfault in some test orders on ROCm 7 (round 3: deterministic after
     # tests/test_conv_gpu.py, never when the test ran alone).  The replayed graph is a chain either way — replay was measured SLOWER than eager launches

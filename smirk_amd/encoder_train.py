@@ -53,10 +53,10 @@ class _EncOps(_Ops):
         need = self.lib.smirk_dwconv3x3_wgrad_workspace_bytes(C)
         if self.dw_ws is None or self.dw_ws.numel() < need:
             self.dw_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        dw = torch.empty(9, C, device=self.dev)
-        L.check(self.lib.smirk_dwconv3x3_wgrad_split16(L.ptr(dz), L.ptr(x), L.ptr(dw), B, H, W, C, stride, L.ptr(self.dw_ws, torch.uint8), self.dw_ws.numel(),
-                                                       self.st))
-        return dw.t().reshape(C, 1, 3, 3)
+        dw = torch.empty(C, 1, 3, 3, device=self.dev)                 # the parameter's own layout: no transpose-copy afterwards
+        L.check(self.lib.smirk_dwconv3x3_wgrad_param_split16(L.ptr(dz), L.ptr(x), L.ptr(dw), B, H, W, C, stride, L.ptr(self.dw_ws, torch.uint8), self.dw_ws.numel(),
+                                                             self.st))
+        return dw
 
 
 def _pw(conv):
@@ -98,7 +98,7 @@ class BackboneTrainFunction(torch.autograd.Function):
         ops.plan = plan
         tape = []
         c0 = backbone.conv_stem.out_channels
-        wst = backbone.conv_stem.weight.detach().float().permute(0, 2, 3, 1).reshape(c0, 27).contiguous()
+        wst = plan.request_special(ops, backbone.conv_stem.weight, L.PACK_STEM)[0]          # [c0][(ky,kx,c)] fp32, by the plan's one packing launch
         z = torch.empty(B, (H + 1) // 2, (W + 1) // 2, c0, device=img.device)
         L.check(lib.smirk_stem_conv_s2_raw_split16(L.ptr(img), L.ptr(wst), L.ptr(z), B, H, W, c0, st))
         x, mu, iv = ops.bn_forward(z, backbone.bn1, True)
@@ -106,7 +106,7 @@ class BackboneTrainFunction(torch.autograd.Function):
         for stage in backbone.blocks:
             for blk in stage:
                 if blk.kind == "ds":
-                    wdw = _dw(blk.conv_dw)
+                    wdw = plan.request_special(ops, blk.conv_dw.weight, L.PACK_DEPTHWISE)[0]           # [9][C] fp32 (the plan's one packing launch)
                     z1 = ops.depthwise(x, wdw, blk.stride)
                     y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
                     wf, wt = ops.pack(blk.conv_pw.weight)
@@ -117,7 +117,7 @@ class BackboneTrainFunction(torch.autograd.Function):
                     wf1, wt1 = ops.pack(blk.conv_pw.weight)
                     z1, s1 = ops.pointwise_stats(x, wf1, blk.conv_pw.out_channels)
                     y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True, stats=s1)
-                    wdw = _dw(blk.conv_dw)
+                    wdw = plan.request_special(ops, blk.conv_dw.weight, L.PACK_DEPTHWISE)[0]
                     z2 = ops.depthwise(y1, wdw, blk.stride)
                     y2, m2, i2 = ops.bn_forward(z2, blk.bn2, True)
                     wf3, wt3 = ops.pack(blk.conv_pwl.weight)

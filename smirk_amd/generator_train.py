@@ -268,6 +268,36 @@ class PackPlan:
         self.bufs.append((f, d))
         return f, d
 
+    def request_special(self, ops, weight, kind):
+        """weights that are not plain nn.Conv2d kernels, re-laid-out by the same one launch (SmirkPackJob kinds, include/smirk_hip.h):
+        PACK_DEPTHWISE [C,1,3,3] -> fp32 [9][C];  PACK_STEM [Cout,3,3,3] -> fp32 [Cout][(ky,kx,c)];  PACK_CONVT2X2 [Cin,Cout,2,2] -> (split16 [(dydx,co)][ci],
+        split16 [ci][(dydx,co)]).  First pass: computed with torch ops and recorded; afterwards the plan's buffers, refreshed by PackPlan.run."""
+        if self.sealed:
+            f, d = self.bufs[self.cursor]
+            self.cursor += 1
+            return f, d
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise L.SmirkHipError("PackPlan needs contiguous fp32 conv weights")
+        if kind == L.PACK_DEPTHWISE:
+            C = w.shape[0]
+            f, d, n = w.reshape(C, 9).t().contiguous(), None, 9 * C // 8
+            job = (w.data_ptr(), f, d, C, 1, 0, 1, kind, 8, n)
+        elif kind == L.PACK_STEM:
+            c0 = w.shape[0]
+            f, d, n = w.permute(0, 2, 3, 1).reshape(c0, 27).contiguous(), None, c0 * 27
+            job = (w.data_ptr(), f, d, c0, 3, 0, 3, kind, 8, n)
+        elif kind == L.PACK_CONVT2X2:
+            ci, co = w.shape[0], w.shape[1]
+            f = _split16(w.permute(2, 3, 1, 0).reshape(4 * co, ci).contiguous())
+            d = _split16(w.permute(0, 2, 3, 1).reshape(ci, 4 * co).contiguous())
+            job = (w.data_ptr(), f, d, ci, co, 0, co, kind, 8, 2 * (4 * co * ci // 8))
+        else:
+            raise L.SmirkHipError(f"unknown pack job kind {kind}")
+        self.jobs.append(job)
+        self.bufs.append((f, d))
+        return f, d
+
     def seal(self, params, device):
         arr = (L.SmirkPackJob * len(self.jobs))()
         start = 0
@@ -363,10 +393,9 @@ class GeneratorTrainFunction(torch.autograd.Function):
         d = b
         for lvl, skip, div, c in ((4, e4, 16, 8 * f), (3, e3, 8, 4 * f), (2, e2, 4, 2 * f), (1, e1, 2, f)):
             up = getattr(module, f"upconv{lvl}")
-            wt = up.weight.detach().float()                                # [Cin, Cout, 2, 2]
-            wup = _split16(wt.permute(2, 3, 1, 0).reshape(4 * wt.shape[1], wt.shape[0]).contiguous())
+            wup, wupd = plan.request_special(ops, up.weight, L.PACK_CONVT2X2)   # [Cin, Cout, 2, 2] -> forward 1x1 image, data-gradient image (same launch as every other weight)
             u = ops.conv(d, None, wup, B, H // div, W // div, c, k=1, convt=True, shift=up.bias.detach().float().contiguous())
-            tape.append(("up", (up,), (d,), (H // div, W // div, 2 * c, c)))
+            tape.append(("up", (up,), (d, wupd), (H // div, W // div, 2 * c, c)))
             d = block(getattr(module, f"decoder{lvl}"), f"dec{lvl}", u, skip, 2 * H // div, 2 * W // div, c)
         wf = module.conv.weight.detach().float().reshape(module.out_channels, f).contiguous()
         bf = module.conv.bias.detach().float().contiguous()
@@ -456,14 +485,13 @@ class GeneratorTrainFunction(torch.autograd.Function):
                     lvl += 1
                 g = g0
             elif kind == "up":
-                (up,), (xin_,), (h, w, cin, cout) = rec[1], rec[2], rec[3]
+                (up,), (xin_, wd), (h, w, cin, cout) = rec[1], rec[2], rec[3]
                 s2d = torch.empty(B, h, w, 4 * cout, device=y.device)
                 L.check(lib.smirk_space_to_depth2_split16(L.ptr(g), L.ptr(s2d), B, h, w, cout, st))
                 if need(up.bias):
                     grads[id(up.bias)] = ops.colsum(g)
                 if need(up.weight):                                        # packed [Cin][(dy,dx,co)] -> the parameter's [Cin][Cout][2][2] in the reduction itself
                     grads[id(up.weight)] = ops.wgrad_param(xin_, s2d, B, h, w, cin, 4 * cout, 1, _grad_like(up.weight), layout=2)
-                wd = _split16(up.weight.detach().float().permute(0, 2, 3, 1).reshape(cin, 4 * cout).contiguous())
                 g = ops.conv(s2d, None, wd, B, h, w, cin, k=1)
             elif kind == "res":
                 _, (ca, na, cbv, nbv), (bin_, za, mua, iva, ya, zb, mub, ivb, wda, wdb), (h, w, c) = rec

@@ -527,3 +527,38 @@ def _desc(B, H, W, cin, cout, k):
     d.pad_t = d.pad_l = (k - 1) // 2
     d.Ho, d.Wo, d.pad_mode, d.act, d.out_mode = H, W, L.PAD_ZERO, L.ACT_NONE, L.OUT_NHWC
     return d
+
+
+def test_pack_plan_relayouts_depthwise_stem_and_transposed_conv_weights_in_its_one_launch():
+    """round 6: the depthwise [C,1,3,3] -> [9][C], stem [Cout,3,3,3] -> [Cout][(ky,kx,c)] and ConvTranspose2d [Cin,Cout,2,2] -> (forward 1x1 image, data-gradient image)
+    re-layouts that a training step needs ride in the PackPlan's single launch (SmirkPackJob kinds) instead of ~6 ATen launches each: the kernel's images are bitwise the
+    torch formulation's, for weights that CHANGED since the plan was sealed (the optimiser step), mixed with ordinary convolution jobs"""
+    from smirk_amd import _lib as L
+    T, ops = _ops()
+    g = _gen(99)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.3).cuda()
+    w_dw, w_c, w_st, w_ct, w_dw2 = mk(72, 1, 3, 3), mk(64, 32, 3, 3), mk(16, 3, 3, 3), mk(64, 32, 2, 2), mk(960, 1, 3, 3)
+    plan = T.PackPlan()
+    ops.plan = plan
+
+    def requests():
+        return [plan.request_special(ops, w_dw, L.PACK_DEPTHWISE), plan.request(ops, w_c, 0, None, None, True, True), plan.request_special(ops, w_st, L.PACK_STEM),
+                plan.request_special(ops, w_ct, L.PACK_CONVT2X2), plan.request_special(ops, w_dw2, L.PACK_DEPTHWISE)]
+
+    first = requests()                                                          # recording pass: torch formulation
+    plan.seal([w_dw, w_c, w_st, w_ct, w_dw2], torch.device("cuda"))
+    with torch.no_grad():
+        for w in (w_dw, w_c, w_st, w_ct, w_dw2):
+            w.mul_(-1.7).add_(0.05)                                             # "the optimiser stepped": same storage, new values
+    want = [(w_dw.reshape(72, 9).t().contiguous(), None), (T._pack_fwd(w_c), T._pack_dgrad(w_c)), (w_st.permute(0, 2, 3, 1).reshape(16, 27).contiguous(), None),
+            (T._split16(w_ct.permute(2, 3, 1, 0).reshape(4 * 32, 64).contiguous()), T._split16(w_ct.permute(0, 2, 3, 1).reshape(64, 4 * 32).contiguous())),
+            (w_dw2.reshape(960, 9).t().contiguous(), None)]
+    plan.run(ops)                                                               # ONE launch
+    got = requests()
+    torch.cuda.synchronize()
+    for (gf, gd), (wf, wd), (ff, fd) in zip(got, want, first):
+        assert gf.data_ptr() == ff.data_ptr()                                   # the plan hands out its own buffers again
+        assert gf.shape == wf.shape and torch.equal(gf.view(torch.int32), wf.view(torch.int32))
+        assert (gd is None) == (wd is None)
+        if wd is not None:
+            assert gd.shape == wd.shape and torch.equal(gd.view(torch.int32), wd.view(torch.int32))
