@@ -562,3 +562,13 @@ def test_pack_plan_relayouts_depthwise_stem_and_transposed_conv_weights_in_its_o
         assert (gd is None) == (wd is None)
         if wd is not None:
             assert gd.shape == wd.shape and torch.equal(gd.view(torch.int32), wd.view(torch.int32))
+
+
+@pytest.mark.parametrize("shape,relu,res", [((3, 6, 10, 32), True, False), ((2, 4, 4, 512), False, True), ((2, 40, 40, 72), True, False), ((5, 7, 7, 960), False, False)])
+def test_batchnorm_three_launch_form_still_matches_float64(shape, relu, res, monkeypatch):
+    """round 6 folded the finalisation of the statistics (forward) and of the two backward sums into the element-wise kernels for tensors of <= 64 MB
+    (bn_apply_fin_kernel / bn_backward_apply_fin_kernel: every other BatchNorm test above now runs that form).  The three-launch form that the U-Net's large
+    tensors keep is selected here with $SMIRK_BN_FIN_UNFUSED and held to the same float64 reference."""
+    monkeypatch.setenv("SMIRK_BN_FIN_UNFUSED", "1")
+    T, ops = _ops()
+    _batchnorm_case(T, ops, shape, relu, res)
