@@ -416,12 +416,16 @@ int smirk_bn_train_forward_split16(const void* z, size_t M, int C, const float* 
  * smirk_conv_igemm_stats_split16: the raw convolution of smirk_conv_igemm_f16x3 / _f16x1 (no scale / shift / residual / activation) that also writes per-tile partial
  * column sums (sum z, sum z^2) of its output: stats[rows][Cout][2] fp32, buffer of smirk_conv_stats_rows_max(d) rows; *rows (host int) = rows written, or 0 when the
  * kernel that serves this shape leaves no statistics (the caller then uses smirk_bn_train_forward_split16, which reduces the stored tensor).
- * smirk_bn_train_forward_partials_split16: smirk_bn_train_forward_split16 with the statistics taken from those P partial rows (fixed-order fp64 reduction). */
+ * smirk_bn_train_forward_partials_split16: smirk_bn_train_forward_split16 with the statistics taken from those P partial rows (fixed-order fp64 reduction);
+ * partials_fp64 = 0: the convolutions' fp32 rows, 1: fp64 stage-1 rows of a reduction kernel. */
 size_t smirk_conv_stats_rows_max(const SmirkConvDesc* d);
 int smirk_conv_igemm_stats_split16(const SmirkConvDesc* d, const void* in0, const void* in1, const void* w, void* out, float* stats, int* rows, int x1, void* stream);
 int smirk_bn_train_forward_partials_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu, float eps,
                                             float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, float* save_mean,
-                                            float* save_var, float* save_invstd, void* y, const float* partials, int P, void* stream);
+                                            float* save_var, float* save_invstd, void* y, const void* partials, int P, int partials_fp64, void* stream);
+/* the depthwise convolutions of the backbones' blocks in train mode: raw output + the stage-1 partial sums of its statistics in ONE launch (fp64 rows [rows][C][2],
+ * buffer of smirk_train_reduce_workspace_bytes(C) bytes; consumed by the entry above with partials_fp64 = 1) */
+int smirk_dwconv3x3_stats_split16(const void* in, const float* w /*[9][C]*/, void* out, int B, int H, int W, int C, int stride, double* part, int* rows, void* stream);
 /* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
 int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, int relu, void* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);

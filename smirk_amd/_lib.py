@@ -142,7 +142,8 @@ _SIGS = {
     "smirk_train_reduce_workspace_bytes": (_sz, [_i]),
     "smirk_conv_stats_rows_max": (_sz, [C.POINTER(SmirkConvDesc)]),
     "smirk_conv_igemm_stats_split16": (_i, [C.POINTER(SmirkConvDesc), _p, _p, _p, _p, _p, C.POINTER(C.c_int), _i, _p]),
-    "smirk_bn_train_forward_partials_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "smirk_bn_train_forward_partials_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "smirk_dwconv3x3_stats_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, C.POINTER(C.c_int), _p]),
     "smirk_bn_train_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _i, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_train_backward_split16": (_i, [_p, _p, _sz, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "smirk_bn_eval_forward_split16": (_i, [_p, _sz, _i, _p, _p, _p, _p, _p, _i, C.c_float, _p, _p, _p, _p]),

@@ -44,17 +44,9 @@ inline unsigned row_blocks(size_t M, int RPB) {                             // b
 // statistics pass and four in the apply kernels: bn_apply 3.96 -> 4.40 ms per training step, the backward sums 3.26 -> 3.69 ms, the statistics pass unchanged — the
 // extra registers cost more occupancy than the loads in flight bought — and went back to this.)
 inline unsigned red_blocks(size_t M, int C, int RPB) {
+    (void)C;
     const size_t by_rows = (M + RPB - 1) / RPB;
-    size_t nb = by_rows > RED_BLOCKS ? RED_BLOCKS : (by_rows ? by_rows : 1);
-    // tensors that take the one-launch finalise + apply (<= 64 MB: the backbones' layers): every element-wise workgroup re-reads the partial rows of its channels,
-    // so keep them few — about one stage-1 block per 64 KB of tensor, at least 32
-    const size_t bytes = M * (size_t)C * 4;
-    if (bytes <= ((size_t)64 << 20) && getenv("SMIRK_BN_FIN_UNFUSED") == nullptr) {
-        size_t want = bytes / 65536;
-        if (want < 32) want = 32;
-        if (nb > want) nb = want;
-    }
-    return (unsigned)nb;
+    return (unsigned)(by_rows > RED_BLOCKS ? RED_BLOCKS : (by_rows ? by_rows : 1));
 }
 inline unsigned blocks_for(size_t items, unsigned cap) {
     const size_t g = (items + 255) / 256;
@@ -313,158 +305,10 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
     bn_backward_apply_body(z, dy, M, G, inv_n, mean, invstd, gamma, beta, sum_dy, sum_dy_xhat, relu, dz);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Finalise + apply in ONE launch, for the layers whose statistics arrive as FEW partial rows (round 6).
-// The three-launch BatchNorm spends a dependent launch on a kernel with microseconds of work (bn_finalize / colsum_stage2: 279 of them per training step, ~6 us
-// each + the gap in front of the launch that waits for them), almost all of it on the backbones' 14 x 14 / 7 x 7 tensors.  Here the element-wise kernel's
-// workgroups each own a COLUMN BLOCK of <= 32 channels (4 groups) and a row range, and every workgroup first reduces the partial rows of ITS 32 channels itself —
-// P x 256 bytes of L2 hits, in the fixed order of the stand-alone finalisation (row lanes 0..3 ascending, eight interleaved fp64 chains each), so every workgroup
-// computes bit-identical statistics and the result equals the three-launch form's up to the grouping of the fp64 sums.  The redundant reads are bounded by the
-// dispatcher: only P <= FIN_MAX_P partial rows take this path, and the row range per workgroup is chosen so that they stay well below the tensor's own traffic.
-// The workgroup that owns row block 0 of a column block also publishes what the backward pass and the module need (mean / var / invstd, running statistics,
-// num_batches_tracked; dgamma / dbeta in the backward form).
-//   PT = float : partial rows [P][C][2] = (sum z, sum z^2) from the convolution epilogues (ConvArgs::stats)
-//   PT = double: partial rows [P][C][2] from colsum_stage1 (MODE 0: statistics; MODE 1: sum dyh, sum dyh * xhat)
-// ---------------------------------------------------------------------------------------------------------------------------------
-#define FIN_MAX_P 512
-template <typename PT>
-__device__ __forceinline__ void fin_reduce_block(const PT* __restrict__ part, int P, int C, int c0, int nch, double (*red)[64], double* out /*[64] in LDS*/) {
-    // 256 threads = 64 columns (32 channels x 2 sums) x 4 row lanes
-    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (col < nch * 2) {
-        const PT* p = part + (size_t)c0 * 2 + col;
-        int k = rl;
-        for (; k + 7 * 4 < P; k += 8 * 4) {
-            PT v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 4 * u) * C * 2];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += (double)v[u];
-        }
-        for (int u = 0; k < P; k += 4, ++u) s[u] += (double)p[(size_t)k * C * 2];
-    }
-    red[rl][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    __syncthreads();
-    if (threadIdx.x < 64) out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    __syncthreads();
-}
-
-template <typename PT>
-__global__ __launch_bounds__(256) void bn_apply_fin_kernel(const float* __restrict__ z, size_t M, int G, const PT* __restrict__ part, int P, double n, float eps,
-                                                           float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ residual, int relu, float* __restrict__ y, float* __restrict__ mean_out,
-                                                           float* __restrict__ var_out, float* __restrict__ invstd_out, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, long long* __restrict__ nbt, int rows_per_block) {
-    __shared__ double red[4][64];
-    __shared__ double sums[64];
-    __shared__ float smu[32], siv[32];
-    const int C = G * 8, c0 = blockIdx.x * 32, nch = min(32, C - c0), ng = nch / 8;
-    fin_reduce_block<PT>(part, P, C, c0, nch, red, sums);
-    if (threadIdx.x < nch) {
-        const double m = sums[threadIdx.x * 2] / n;
-        double v = sums[threadIdx.x * 2 + 1] / n - m * m;
-        if (v < 0.0) v = 0.0;
-        const float mf = (float)m, ivf = (float)(1.0 / sqrt(v + (double)eps));
-        smu[threadIdx.x] = mf; siv[threadIdx.x] = ivf;
-        if (blockIdx.y == 0) {                                       // one publisher per channel
-            const int c = c0 + threadIdx.x;
-            mean_out[c] = mf; var_out[c] = (float)v; invstd_out[c] = ivf;
-            if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
-            if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
-            if (nbt && c == 0) *nbt += 1;
-        }
-    }
-    __syncthreads();
-    // element-wise part: thread = (group gl of the column block, row lane); 256 / ng rows in flight per iteration
-    const int gl = threadIdx.x % ng, rlane = threadIdx.x / ng, RPI = 256 / ng;
-    if (rlane >= RPI) return;
-    const int g = blockIdx.x * 4 + gl;
-    float mu[8], is[8], ga[8], be[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { mu[q] = smu[gl * 8 + q]; is[q] = siv[gl * 8 + q]; ga[q] = gamma[g * 8 + q]; be[q] = beta[g * 8 + q]; }
-    const size_t r_begin = (size_t)blockIdx.y * rows_per_block, r_end = min(M, r_begin + (size_t)rows_per_block);
-    for (size_t r = r_begin + rlane; r < r_end; r += RPI) {
-        const size_t i = r * G + g;
-        float v[8];
-        load_group(z + i * 8, v);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mu[q]) * is[q] * ga[q] + be[q];
-        if (residual) {
-            float rr[8];
-            load_group(residual + i * 8, rr);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += rr[q];
-        }
-        if (relu) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-        store_group(y + i * 8, v);
-    }
-}
-
-// backward: partial rows = colsum_stage1<1>'s (sum dyh, sum dyh * xhat); dz = gamma * invstd * (dyh - S1 / n - xhat * S2 / n); publishes dbeta = S1, dgamma = S2
-__global__ __launch_bounds__(256) void bn_backward_apply_fin_kernel(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
-                                                                    const double* __restrict__ part, int P, float inv_n, const float* __restrict__ mean,
-                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                                    const float* __restrict__ beta, int relu, float* __restrict__ dz,
-                                                                    float* __restrict__ dbeta, float* __restrict__ dgamma, int rows_per_block) {
-    __shared__ double red[4][64];
-    __shared__ double sums[64];
-    __shared__ float ss1[32], ss2[32];
-    const int C = G * 8, c0 = blockIdx.x * 32, nch = min(32, C - c0), ng = nch / 8;
-    fin_reduce_block<double>(part, P, C, c0, nch, red, sums);
-    if (threadIdx.x < nch) {
-        const float a = (float)sums[threadIdx.x * 2], b = (float)sums[threadIdx.x * 2 + 1];     // (the fp32 values colsum_stage2 hands the element-wise kernel)
-        ss1[threadIdx.x] = a; ss2[threadIdx.x] = b;
-        if (blockIdx.y == 0) { dbeta[c0 + threadIdx.x] = a; dgamma[c0 + threadIdx.x] = b; }
-    }
-    __syncthreads();
-    const int gl = threadIdx.x % ng, rlane = threadIdx.x / ng, RPI = 256 / ng;
-    if (rlane >= RPI) return;
-    const int g = blockIdx.x * 4 + gl;
-    float mu[8], is[8], ga[8], be[8], s1[8], s2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int c = g * 8 + q;
-        mu[q] = mean[c]; is[q] = invstd[c]; ga[q] = gamma[c]; be[q] = beta[c]; s1[q] = ss1[gl * 8 + q] * inv_n; s2[q] = ss2[gl * 8 + q] * inv_n;
-    }
-    const size_t r_begin = (size_t)blockIdx.y * rows_per_block, r_end = min(M, r_begin + (size_t)rows_per_block);
-    for (size_t r = r_begin + rlane; r < r_end; r += RPI) {
-        const size_t i = r * G + g;
-        float v[8], d[8];
-        load_group(z + i * 8, v);
-        load_group(dy + i * 8, d);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float xh = (v[q] - mu[q]) * is[q];
-            const float dh = (relu && !(xh * ga[q] + be[q] > 0.f)) ? 0.f : d[q];
-            v[q] = ga[q] * is[q] * (dh - s1[q] - xh * s2[q]);
-        }
-        store_group(dz + i * 8, v);
-    }
-}
-// row blocks of the fused kernels: enough workgroups to fill the chip, each streaming at least ~8x what it re-reads of the partial rows (P x 256 B)
-static inline void fin_grid(size_t M, int C, int P, size_t part_elem_bytes, unsigned& gx, unsigned& gy, int& rows_per_block) {
-    gx = (unsigned)((C + 31) / 32);
-    const size_t want = 1024 / gx ? 1024 / gx : 1;                                  // ~4 workgroups per CU in all
-    const size_t min_rows = (size_t)P * 64 * part_elem_bytes * 8 / (32 * 4 * 2) + 1; // row range whose (read + write) traffic is 8x the partial rows'
-    size_t rpb = (M + want - 1) / want;
-    if (rpb < min_rows) rpb = min_rows;
-    if (rpb < 64) rpb = 64;
-    if (rpb > M) rpb = M;
-    rows_per_block = (int)rpb;
-    gy = (unsigned)((M + rpb - 1) / rpb);
-}
-// does a layer take the one-launch finalise + apply?  (few partial rows, and a tensor small enough that the column-block mapping — 4 groups of a row per
-// workgroup instead of whole rows — is not what its streaming rate depends on: the U-Net's 100-400 MB tensors keep the three-launch form)
-#define FIN_MAX_BYTES ((size_t)64 << 20)
-static inline bool fin_eligible(size_t M, int C, int P) {
-    const bool off = getenv("SMIRK_BN_FIN_UNFUSED") != nullptr;                     // A/B switch (read per call: tests toggle it)
-    return !off && P <= FIN_MAX_P && M * (size_t)C * 4 <= FIN_MAX_BYTES && M <= 0x7fffffff;
-}
-
+// (Round 6 built a one-launch "finalise + apply" for tensors of <= 64 MB — element-wise workgroups owning a 32-channel column block and a row range, each reducing the
+// partial rows of its own channels first — to drop the 279 tiny stage-2 launches of a training step.  Measured on the MI355X: the column-block mapping (four lanes per
+// 128-byte row segment, rows C * 4 bytes apart) streams at 0.6-0.8 TB/s where the whole-row mapping below reaches 3-4.5 TB/s; the step went 41.2 -> 45.7 ms.  Removed
+// again: on this part a dependent launch stays the cheap way to hand 2 KB of statistics to 2048 workgroups.  profiles/r06d_bench_train64_fin.txt)
 // 2x2/2 max-pool backward: the gradient goes to the first maximum of the window in scan order (ATen's max_pool2d picks `val > max`), plus an
 // optional second gradient of the same tensor (the U-Net skip connection) added in.  x, dx [B][H][W][G*8]; dy [B][H/2][W/2][G*8]
 __global__ __launch_bounds__(256) void maxpool_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ add,
@@ -1301,14 +1145,6 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
     SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
                  (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
-    if (fin_eligible(M, C, (int)nb)) {                               // finalise inside the element-wise kernel: one dependent launch less
-        unsigned gx, gy; int rpb;
-        fin_grid(M, C, (int)nb, sizeof(double), gx, gy, rpb);
-        smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
-        SMIRK_LAUNCH(bn_apply_fin_kernel<double>, dim3(gx, gy), dim3(256), 0, st, (const float*)z, M, G, (const double*)ws, (int)nb, (double)M, eps, momentum, gamma,
-                     beta, (const float*)residual, relu, (float*)y, save_mean, save_var, save_invstd, running_mean, running_var, num_batches_tracked, rpb);
-        return smirk_launch_status();
-    }
     SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
                  save_invstd, running_mean, running_var, num_batches_tracked);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
@@ -1321,19 +1157,21 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
  * finalise from the P partial rows (fixed-order fp64) + apply — the statistics pass over z and one launch are gone. */
 extern "C" int smirk_bn_train_forward_partials_split16(const void* z, size_t M, int C, const float* gamma, const float* beta, const void* residual, int relu,
                                                        float eps, float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
-                                                       float* save_mean, float* save_var, float* save_invstd, void* y, const float* partials, int P, void* stream) {
-    if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !partials || P <= 0 || M == 0 || C <= 0 || C % 8 || C / 8 > 256)
+                                                       float* save_mean, float* save_var, float* save_invstd, void* y, const void* partials_v, int P,
+                                                       int partials_fp64, void* stream) {
+    if (!z || !gamma || !beta || !save_mean || !save_var || !save_invstd || !y || !partials_v || P <= 0 || M == 0 || C <= 0 || C % 8 || C / 8 > 256)
         return SMIRK_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
-    if (fin_eligible(M, C, P)) {
-        unsigned gx, gy; int rpb;
-        fin_grid(M, C, P, sizeof(float), gx, gy, rpb);
+    if (partials_fp64) {                                             // stage-1 rows of a reduction kernel (smirk_dwconv3x3_stats_split16): [P][C][2] doubles
+        SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partials_v, P, C, (double)M, eps, momentum, save_mean, save_var,
+                     save_invstd, running_mean, running_var, num_batches_tracked);
         smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
-        SMIRK_LAUNCH(bn_apply_fin_kernel<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)z, M, G, partials, P, (double)M, eps, momentum, gamma, beta,
-                     (const float*)residual, relu, (float*)y, save_mean, save_var, save_invstd, running_mean, running_var, num_batches_tracked, rpb);
+        SMIRK_LAUNCH(bn_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, M, G, (const float*)save_mean, (const float*)save_invstd, gamma,
+                     beta, (const float*)residual, relu, (float*)y);
         return smirk_launch_status();
     }
+    const float* partials = (const float*)partials_v;
     SMIRK_LAUNCH(bn_finalize_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, partials, P, C, (double)M, eps, momentum, save_mean, save_var, save_invstd,
                  running_mean, running_var, num_batches_tracked);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
@@ -1352,14 +1190,6 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     const int G = C / 8, RPB = 256 / G;
     const unsigned nb = red_blocks(M, C, RPB);
     SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
-    if (fin_eligible(M, C, (int)nb)) {                               // stage 2 inside the element-wise kernel
-        unsigned gx, gy; int rpb;
-        fin_grid(M, C, (int)nb, sizeof(double), gx, gy, rpb);
-        smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
-        SMIRK_LAUNCH(bn_backward_apply_fin_kernel, dim3(gx, gy), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, (const double*)ws, (int)nb,
-                     (float)(1.0 / (double)M), save_mean, save_invstd, gamma, beta, relu, (float*)dz, dbeta, dgamma, rpb);
-        return smirk_launch_status();
-    }
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
     SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G,

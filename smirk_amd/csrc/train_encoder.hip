@@ -286,11 +286,83 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     }
 }
 
+// Train-mode depthwise 3x3 (raw output: BatchNorm takes batch statistics afterwards) that ALSO leaves the statistics' stage-1 partial sums (round 6).
+// Thread = (8-channel group g = tid % G, row lane tid / G), like the column reductions of train.hip: a thread keeps its group for the whole launch, so the 72
+// weights of the group are loaded ONCE into registers (the inference kernel re-fetches eight per tap and item and spends a 32-bit division per item on
+// e -> (pixel, group)), walks output pixels r = block * RPB + lane + k * stride, and adds what it stores into per-thread fp64 sums; the block's sums are combined in
+// a fixed order through LDS exactly as colsum_stage1 does and written as one partial row [block][C][2] (sum z, sum z^2) — the layout bn_finalize_kernel /
+// bn_apply_fin_kernel<double> consume.  The separate statistics pass over the depthwise output (41 launches and a full read of the tensor per step) is gone.
+__global__ __launch_bounds__(256) void dwconv3x3_train_kernel(const float* __restrict__ in, const float* __restrict__ w /*[9][C]*/, float* __restrict__ out, int B,
+                                                              int H, int W, int G, int stride, double* __restrict__ part /*[blocks][C][2]*/) {
+    __shared__ double red[256 * 16];
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    const int pt = pad_lead(H, stride), pl = pad_lead(W, stride), C = G * 8;
+    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
+    const bool active = rl < RPB;
+    float wt[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const f32x4 w0 = *(const f32x4*)(w + k * C + g * 8), w1 = *(const f32x4*)(w + k * C + g * 8 + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wt[k][q] = w0[q]; wt[k][4 + q] = w1[q]; }
+    }
+    double s1[8], s2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+    const unsigned M = (unsigned)B * Ho * Wo, HoWo = (unsigned)Ho * Wo;
+    for (unsigned r = blockIdx.x * RPB + rl; active && r < M; r += gridDim.x * RPB) {
+        const unsigned b = r / HoWo, rem = r - b * HoWo;
+        const int oy = (int)(rem / Wo), ox = (int)(rem - (unsigned)oy * Wo);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - pt + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - pl + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float* p = in + ((((size_t)b * H + iy) * W + ix) * G + g) * 8;
+                const half8 hi = *(const half8*)p, lo = *(const half8*)(p + 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(join1(hi[q], lo[q]), wt[ky * 3 + kx][q], acc[q]);
+            }
+        }
+        store_group(out + ((size_t)r * G + g) * 8, acc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] += (double)acc[q]; s2[q] += (double)acc[q] * (double)acc[q]; }
+    }
+    for (int q = 0; q < 8; ++q) { red[tid * 16 + q * 2] = s1[q]; red[tid * 16 + q * 2 + 1] = s2[q]; }
+    __syncthreads();
+    for (int o = tid; o < G * 16; o += 256) {                         // fixed order: row lane 0, 1, ... of each (group, channel, which) column
+        const int gg = o >> 4, k = o & 15;
+        double a = 0.0;
+        for (int rr = 0; rr < RPB; ++rr) a += red[(rr * G + gg) * 16 + k];
+        part[((size_t)blockIdx.x * G * 8 + gg * 8 + (k >> 1)) * 2 + (k & 1)] = a;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------------------
+/* Train-mode depthwise 3x3 (smirk_encoder.py:7-12's timm blocks after `self.train()`): the raw convolution + the stage-1 partial sums of its output for the
+ * BatchNorm that follows.  part: [rows][C][2] fp64, at least smirk_train_reduce_workspace_bytes(C) bytes (<= 512 rows); *rows = rows written. */
+extern "C" int smirk_dwconv3x3_stats_split16(const void* in, const float* w, void* out, int B, int H, int W, int C, int stride, double* part, int* rows,
+                                             void* stream) {
+    if (!in || !w || !out || !part || !rows || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C / 8 > 256 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
+    const int G = C / 8, RPB = 256 / G;
+    const size_t M = (size_t)B * ((H + stride - 1) / stride) * ((W + stride - 1) / stride);
+    if (M > 0x7fffffffull || (size_t)B * H * W > 0x7fffffffull) return SMIRK_ERR_UNSUPPORTED;
+    size_t nb = (M + RPB - 1) / RPB;
+    if (nb > 512) nb = 512;
+    *rows = (int)nb;
+    smirk_prof_next(nullptr, 18.0 * (double)M * C, 4.0 * ((double)B * H * W * C + (double)M * C));
+    SMIRK_LAUNCH(dwconv3x3_train_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)in, w, (float*)out, B, H, W, G, stride, part);
+    return smirk_launch_status();
+}
+
 extern "C" int smirk_dwconv3x3_dgrad_split16(const void* dz, const float* w, const void* add, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     if (!dz || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
     smirk_prof_next(nullptr, 18.0 * B * H * W * C / (stride * stride), 4.0 * B * H * W * C * (1.0 + 1.0 / (stride * stride) + (add ? 1.0 : 0.0)));

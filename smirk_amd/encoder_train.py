@@ -43,6 +43,17 @@ class _EncOps(_Ops):
         L.check(self.lib.smirk_dwconv3x3_split16(P(x), P(w9c), P(self.ones[C]), P(self.zeros[C]), P(out), B, H, W, C, stride, 0, self.st))
         return out
 
+    def depthwise_stats(self, x, w9c, stride):
+        """train mode: the raw depthwise convolution + the stage-1 partial sums of its output's statistics in one launch -> (z, (fp64 partial rows, count) or None)"""
+        if not self.fuse_stats:
+            return self.depthwise(x, w9c, stride), None
+        B, H, W, C = x.shape
+        out = torch.empty(B, (H + stride - 1) // stride, (W + stride - 1) // stride, C, device=self.dev)
+        part = torch.empty(512 * C * 2, dtype=torch.float64, device=self.dev)
+        rows = L.C.c_int(0)
+        L.check(self.lib.smirk_dwconv3x3_stats_split16(L.ptr(x), L.ptr(w9c), L.ptr(out), B, H, W, C, stride, L.ptr(part, torch.float64), L.C.byref(rows), self.st))
+        return out, (part, rows.value)
+
     def depthwise_dgrad(self, dz, w9c, add, B, H, W, C, stride):
         dx = torch.empty(B, H, W, C, device=self.dev)
         L.check(self.lib.smirk_dwconv3x3_dgrad_split16(L.ptr(dz), L.ptr(w9c), L.ptr(add, allow_none=True), L.ptr(dx), B, H, W, C, stride, self.st))
@@ -107,8 +118,8 @@ class BackboneTrainFunction(torch.autograd.Function):
             for blk in stage:
                 if blk.kind == "ds":
                     wdw = plan.request_special(ops, blk.conv_dw.weight, L.PACK_DEPTHWISE)[0]           # [9][C] fp32 (the plan's one packing launch)
-                    z1 = ops.depthwise(x, wdw, blk.stride)
-                    y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True)
+                    z1, sd = ops.depthwise_stats(x, wdw, blk.stride)
+                    y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True, stats=sd)
                     wf, wt = ops.pack(blk.conv_pw.weight)
                     z2, s2 = ops.pointwise_stats(y1, wf, blk.conv_pw.out_channels)
                     out, m2, i2 = ops.bn_forward(z2, blk.bn2, False, residual=x if blk.skip else None, stats=s2)
@@ -118,8 +129,8 @@ class BackboneTrainFunction(torch.autograd.Function):
                     z1, s1 = ops.pointwise_stats(x, wf1, blk.conv_pw.out_channels)
                     y1, m1, i1 = ops.bn_forward(z1, blk.bn1, True, stats=s1)
                     wdw = plan.request_special(ops, blk.conv_dw.weight, L.PACK_DEPTHWISE)[0]
-                    z2 = ops.depthwise(y1, wdw, blk.stride)
-                    y2, m2, i2 = ops.bn_forward(z2, blk.bn2, True)
+                    z2, sd = ops.depthwise_stats(y1, wdw, blk.stride)
+                    y2, m2, i2 = ops.bn_forward(z2, blk.bn2, True, stats=sd)
                     wf3, wt3 = ops.pack(blk.conv_pwl.weight)
                     z3, s3 = ops.pointwise_stats(y2, wf3, blk.conv_pwl.out_channels)
                     out, m3, i3 = ops.bn_forward(z3, blk.bn3, False, residual=x if blk.skip else None, stats=s3)

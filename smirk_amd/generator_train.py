@@ -160,10 +160,11 @@ class _Ops:
         mom = float(bn.momentum) if bn.momentum is not None else (1.0 / max(int(bn.num_batches_tracked), 1) if track else 0.0)
         if stats is not None:                            # the producing convolution left the partial sums of z: finalise from them, no pass over z
             part, rows = stats
+            fp64 = int(part.dtype == torch.float64)
             L.check(self.lib.smirk_bn_train_forward_partials_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
                                                                      float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),
                                                                      P(bn.running_var if track else None, allow_none=True), P(nbt, torch.int64, allow_none=True),
-                                                                     P(mean), P(var), P(inv), P(y), P(part), int(rows), self.st))
+                                                                     P(mean), P(var), P(inv), P(y), P(part, part.dtype), int(rows), fp64, self.st))
             return y, mean, inv
         L.check(self.lib.smirk_bn_train_forward_split16(P(z), M, C, P(bn.weight.detach()), P(bn.bias.detach()), P(residual, allow_none=True), int(relu),
                                                         float(bn.eps), mom, P(bn.running_mean if track else None, allow_none=True),

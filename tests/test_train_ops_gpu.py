@@ -564,11 +564,28 @@ def test_pack_plan_relayouts_depthwise_stem_and_transposed_conv_weights_in_its_o
             assert gd.shape == wd.shape and torch.equal(gd.view(torch.int32), wd.view(torch.int32))
 
 
-@pytest.mark.parametrize("shape,relu,res", [((3, 6, 10, 32), True, False), ((2, 4, 4, 512), False, True), ((2, 40, 40, 72), True, False), ((5, 7, 7, 960), False, False)])
-def test_batchnorm_three_launch_form_still_matches_float64(shape, relu, res, monkeypatch):
-    """round 6 folded the finalisation of the statistics (forward) and of the two backward sums into the element-wise kernels for tensors of <= 64 MB
-    (bn_apply_fin_kernel / bn_backward_apply_fin_kernel: every other BatchNorm test above now runs that form).  The three-launch form that the U-Net's large
-    tensors keep is selected here with $SMIRK_BN_FIN_UNFUSED and held to the same float64 reference."""
-    monkeypatch.setenv("SMIRK_BN_FIN_UNFUSED", "1")
-    T, ops = _ops()
-    _batchnorm_case(T, ops, shape, relu, res)
+@pytest.mark.parametrize("B,H,W,C,stride", [(2, 8, 8, 16, 1), (2, 9, 7, 24, 2), (1, 14, 14, 72, 2), (3, 7, 7, 960, 1), (2, 12, 12, 64, 2), (4, 28, 28, 120, 1), (2, 57, 33, 200, 2)])
+def test_depthwise_train_kernel_output_and_statistics(B, H, W, C, stride):
+    """round 6: dwconv3x3_train_kernel (weights of a lane's channel group held in registers, stage-1 sums of the BatchNorm statistics added while storing): the output is
+    bit-identical to the inference kernel's raw output, the fp64 partial rows add up to the column sums of the stored tensor, and the BatchNorm that consumes them equals
+    the BatchNorm that reduces the stored tensor (channel counts that do not divide 256, odd sizes, both strides)."""
+    E, ops = _enc_ops()
+    g = _gen(H * C + stride + 5)
+    wt = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    xs, _ = _act(torch.randn(B, H, W, C, generator=g))
+    w9c = wt.reshape(C, 9).t().contiguous().cuda()
+    z_ref = ops.depthwise(xs, w9c, stride)
+    z, st = ops.depthwise_stats(xs, w9c, stride)
+    assert torch.equal(z, z_ref) and st is not None
+    part, rows = st
+    zv = _val(z).permute(0, 2, 3, 1).reshape(-1, C)
+    p = part[:rows * C * 2].reshape(rows, C, 2).sum(0).cpu()
+    s1, s2 = zv.sum(0), (zv * zv).sum(0)
+    assert (p[:, 0] - s1).abs().max().item() <= 2e-6 * zv.abs().sum(0).max().item() + 1e-6      # (the sums take z before it is rounded into the split format)
+    assert (p[:, 1] - s2).abs().max().item() <= 4e-6 * s2.max().item() + 1e-9
+    bn, bn2 = torch.nn.BatchNorm2d(C).cuda().train(), torch.nn.BatchNorm2d(C).cuda().train()
+    y_a, mu_a, iv_a = ops.bn_forward(z, bn, True, stats=st)
+    y_b, mu_b, iv_b = ops.bn_forward(z, bn2, True)
+    assert (mu_a - mu_b).abs().max().item() <= 1e-6 * max(1.0, mu_b.abs().max().item()) and ((iv_a - iv_b).abs() / iv_b).max().item() <= 5e-6
+    assert _rel(_val(y_a), _val(y_b)) < 1e-5
+    assert torch.allclose(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7) and int(bn.num_batches_tracked) == 1
