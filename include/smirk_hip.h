@@ -424,7 +424,7 @@ int smirk_bn_train_forward_partials_split16(const void* z, size_t M, int C, cons
                                             float momentum, float* running_mean, float* running_var, long long* num_batches_tracked, float* save_mean,
                                             float* save_var, float* save_invstd, void* y, const void* partials, int P, int partials_fp64, void* stream);
 /* the depthwise convolutions of the backbones' blocks in train mode: raw output + the stage-1 partial sums of its statistics in ONE launch (fp64 rows [rows][C][2],
- * buffer of smirk_train_reduce_workspace_bytes(C) bytes; consumed by the entry above with partials_fp64 = 1) */
+ * buffer of 1024 rows; consumed by the entry above with partials_fp64 = 1; SMIRK_ERR_UNSUPPORTED for inputs of 2 GiB and more) */
 int smirk_dwconv3x3_stats_split16(const void* in, const float* w /*[9][C]*/, void* out, int B, int H, int W, int C, int stride, double* part, int* rows, void* stream);
 /* dy = dL/dy of the forward above (relu: the mask is recomputed from z); writes dz, dgamma[C], dbeta[C].  The residual's gradient is dy itself. */
 int smirk_bn_train_backward_split16(const void* z, const void* dy, size_t M, int C, const float* gamma, const float* beta, const float* save_mean,

@@ -561,8 +561,8 @@ __device__ __forceinline__ half8 wgf_frag(const char* base, int off) {          
     return u.h;
 }
 
-template <int TM, int SUB, bool X1 = false>   // X1: hi x hi only, one MFMA per block (BASELINE config 5's 16-bit class); its own instantiations
-__global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trmap) {
+template <int TM, int SUB, bool X1 = false, int DEPTH = 1>   // X1: hi x hi only, one MFMA per block (BASELINE config 5's 16-bit class); its own instantiations
+__global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trmap) {   // DEPTH: iterations of operand fetches in flight (register queue; see the loop)
     constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
     constexpr int BM = TM / 32 / WAVES_M, BN = 4 / WAVES_N;                 // 32 x 32 MFMA blocks per wave: 2x2 (TM 128), 2x1 (TM 64), 1x1 (TM 32)
     constexpr int GA = TM / 8, AQ = GA / 4, BQ = 4;                         // 8-channel groups / group quads of the A (dz) and B (x, 128 columns) tiles
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
     unsigned oa = (unsigned)(((unsigned long long)p0 * Gout + gco) * 32ull);
     unsigned ob = (unsigned)(((long long)p0 + (long long)(ky - a.pad) * a.W + (kx - a.pad)) * Gin + gci) * 32u;
     const unsigned a_step = (unsigned)(WG_KC * Gout * 32), b_step = (unsigned)(WG_KC * Gin * 32);
-    u32x4_t ra[SUB][2], rb[SUB][2];
-    auto fetch = [&]() {
+    u32x4_t ra0[SUB][2], rb0[SUB][2], ra1[DEPTH == 2 ? SUB : 1][2], rb1[DEPTH == 2 ? SUB : 1][2];
+    auto fetch = [&](u32x4_t (*ra)[2], u32x4_t (*rb)[2]) {
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             const bool live = fc < a.chunks_per_split && fb < a.B;
@@ -645,8 +645,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
         const int gq = wn * BN + j;
         offB[j] = (((gq * 4 + khalf * 2) * 16) + (((r4 + gq) & 3) << 2) + gl) * 16 + (q4 & 1) * 8;
     }
-    fetch();
-    for (int it = 0; it < iters; ++it) {
+    // The operands travel global -> registers -> LDS.  With one iteration of fetches in flight (round 2-5) a workgroup keeps SUB * 16 KB outstanding, two workgroups per
+    // CU 64 KB — against ~2 us of L2 / Infinity-Cache latency that is ~8 TB/s over the chip, exactly the rate the kernel measured (0.10 of the MFMA roof, the
+    // matrix pipe 30 % busy): the kernel is bound by bytes in flight, not by the matrix pipe or the LDS.  DEPTH = 2 keeps a SECOND iteration's fetches in a second
+    // register set (+32 VGPRs; 207 -> ~240 of the 256 a two-workgroup CU allows): the loads issued under iteration `it` are consumed at `it + 2`.
+    auto iteration = [&](int it, u32x4_t (*ra)[2], u32x4_t (*rb)[2]) {
         const int buf = it & 1;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
             *(u32x4_t*)(Bs[buf][s] + wb_hi) = rb[s][0]; *(u32x4_t*)(Bs[buf][s] + wb_lo) = rb[s][1];
         }
         __syncthreads();                       // this stage visible; the stage written next iteration was last read two iterations ago, behind this barrier
-        if (it + 1 < iters) fetch();
+        if (it + DEPTH < iters) fetch(ra, rb);
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             half8 ah[BM], al[BM], bh[BN], bl[BN];
@@ -673,6 +676,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
                     }
                 }
         }
+    };
+    fetch(ra0, rb0);
+    if constexpr (DEPTH == 2) { if (iters > 1) fetch(ra1, rb1); }
+    for (int it = 0; it < iters; it += DEPTH) {
+        iteration(it, ra0, rb0);
+        if constexpr (DEPTH == 2) { if (it + 1 < iters) iteration(it + 1, ra1, rb1); }
     }
     float* out = a.part + (size_t)split * a.Cout * N;
 #pragma unroll
@@ -1276,6 +1285,10 @@ static bool wgrad_halo_ok(int W, int Cout, int Cin, int KH, int reflect) {
 }
 // $SMIRK_WGRAD_F16: "0" = exact-fp32 MFMA kernel (wgrad_kernel), "1" / "2" = split-fp16 x3 kernel with 1 / 2 chunks per barrier (default 2);
 // "+16" (17 / 18) selects the alternative lane geometry of the LDS transpose read (diagnostic)
+static bool wgrad_depth2() {                                       // $SMIRK_WGRAD_DEPTH=1: one iteration of operand fetches in flight (rounds 2-5); default 2 (A/B switch, read per call)
+    const char* e = getenv("SMIRK_WGRAD_DEPTH");
+    return !(e && e[0] == '1');
+}
 static int g_wgrad_mode_override = -1;
 static std::atomic<unsigned long long> g_wgrad_x1_fallbacks{0};
 static int wgrad_f16_mode() {
@@ -1394,6 +1407,7 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         if (x1) {                                                            // (always two chunks per barrier: the measured default)
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 2, true>), grid, dim3(256), 0, st, a, trmap);
             else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 2, true>), grid, dim3(256), 0, st, a, trmap);
+            else if (wgrad_depth2()) SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, true, 2>), grid, dim3(256), 0, st, a, trmap);
             else SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, true>), grid, dim3(256), 0, st, a, trmap);
         } else if ((mode & 15) == 1) {
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 1>), grid, dim3(256), 0, st, a, trmap);
@@ -1402,6 +1416,7 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         } else {
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 2>), grid, dim3(256), 0, st, a, trmap);
             else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 2>), grid, dim3(256), 0, st, a, trmap);
+            else if (wgrad_depth2()) SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, false, 2>), grid, dim3(256), 0, st, a, trmap);
             else SMIRK_LAUNCH((wgrad_f16_kernel<128, 2>), grid, dim3(256), 0, st, a, trmap);
         }
     } else if (TM == 32) SMIRK_LAUNCH(wgrad_kernel<32>, grid, dim3(256), 0, st, a);

@@ -39,17 +39,26 @@ __host__ __device__ inline int pad_lead(int n, int s) {
 }
 
 // dX[b,iy,ix,c] = sum_{ky,kx} dZ[b,oy,ox,c] * w[ky,kx,c]  over the outputs whose tap (ky,kx) reads (iy,ix):  oy*s - pt + ky = iy
+// Thread = (8-channel group g = tid % G, pixel lane tid / G): a thread keeps its group for the whole launch, so the group's 72 weights sit in registers and an item costs
+// two 32-bit divisions (round 5's flat 64-bit index spent three 64-bit divisions and eight weight loads per tap on every item: the kernel was VALU-bound at 1.8 TB/s).
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w /*[9][C]*/, const float* __restrict__ add,
                                                        float* __restrict__ dx, int B, int H, int W, int G, int stride) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const int pt = pad_lead(H, stride), pl = pad_lead(W, stride), C = G * 8;
-    const size_t total = (size_t)B * H * W * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % G);
-        size_t t = i / G;
-        const int ix = (int)(t % W); t /= W;
-        const int iy = (int)(t % H);
-        const size_t b = t / H;
+    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
+    if (rl >= RPB) return;
+    float wt[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const f32x4 w0 = *(const f32x4*)(w + k * C + g * 8), w1 = *(const f32x4*)(w + k * C + g * 8 + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wt[k][q] = w0[q]; wt[k][4 + q] = w1[q]; }
+    }
+    const unsigned M = (unsigned)B * H * W, HW = (unsigned)H * W;
+    for (unsigned r = blockIdx.x * RPB + rl; r < M; r += gridDim.x * RPB) {
+        const unsigned b = r / HW, rem = r - b * HW;
+        const int iy = (int)(rem / W), ix = (int)(rem - (unsigned)iy * W);
+        const size_t i = (size_t)r * G + g;
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
@@ -67,10 +76,9 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
                 const int ox = tx / stride;
                 if (ox >= Wo) continue;
                 float v[8];
-                load_group(dz + (((b * Ho + oy) * Wo + ox) * G + g) * 8, v);
-                const float* ww = w + (ky * 3 + kx) * C + g * 8;
+                load_group(dz + ((((size_t)b * Ho + oy) * Wo + ox) * G + g) * 8, v);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = fmaf(v[q], ww[q], acc[q]);
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(v[q], wt[ky * 3 + kx][q], acc[q]);
             }
         }
         store_group(dx + i * 8, acc);
@@ -310,23 +318,31 @@ __global__ __launch_bounds__(256) void dwconv3x3_train_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < 8; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
     const unsigned M = (unsigned)B * Ho * Wo, HoWo = (unsigned)Ho * Wo;
+    // All 18 loads of a pixel go out before the first is consumed: taps outside the image read through a buffer resource at an out-of-range offset (zeros) instead of
+    // branching around the load (a branch per tap serialises the nine round trips: the first version of this kernel measured 1.1 TB/s, like the inference kernel).
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, (int)((size_t)B * H * W * C * 4), 0x00020000);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     for (unsigned r = blockIdx.x * RPB + rl; active && r < M; r += gridDim.x * RPB) {
         const unsigned b = r / HoWo, rem = r - b * HoWo;
         const int oy = (int)(rem / Wo), ox = (int)(rem - (unsigned)oy * Wo);
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        u32x4_t th[9], tl[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * stride - pt + ky;
-            if (iy < 0 || iy >= H) continue;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * stride - pl + kx;
-                if (ix < 0 || ix >= W) continue;
-                const float* p = in + ((((size_t)b * H + iy) * W + ix) * G + g) * 8;
-                const half8 hi = *(const half8*)p, lo = *(const half8*)(p + 4);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = fmaf(join1(hi[q], lo[q]), wt[ky * 3 + kx][q], acc[q]);
+                const int iy = oy * stride - pt + ky, ix = ox * stride - pl + kx;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const unsigned off = ok ? (unsigned)((((b * H + iy) * W + ix) * G + g) * 32u) : 0x80000000u;
+                th[ky * 3 + kx] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                tl[ky * 3 + kx] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16, 0);
             }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            union { u32x4_t u; half8 h; } uh, ul;
+            uh.u = th[k]; ul.u = tl[k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fmaf(join1(uh.h[q], ul.h[q]), wt[k][q], acc[q]);
         }
         store_group(out + ((size_t)r * G + g) * 8, acc);
 #pragma unroll
@@ -348,15 +364,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_train_kernel(const float* __res
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------------------
 /* Train-mode depthwise 3x3 (smirk_encoder.py:7-12's timm blocks after `self.train()`): the raw convolution + the stage-1 partial sums of its output for the
- * BatchNorm that follows.  part: [rows][C][2] fp64, at least smirk_train_reduce_workspace_bytes(C) bytes (<= 512 rows); *rows = rows written. */
+ * BatchNorm that follows.  part: [rows][C][2] fp64, room for 1024 rows (1024 * C * 16 bytes); *rows = rows written.  SMIRK_ERR_UNSUPPORTED for inputs of 2 GiB and
+ * more (the caller then runs smirk_dwconv3x3_split16 + smirk_bn_train_forward_split16). */
 extern "C" int smirk_dwconv3x3_stats_split16(const void* in, const float* w, void* out, int B, int H, int W, int C, int stride, double* part, int* rows,
                                              void* stream) {
     if (!in || !w || !out || !part || !rows || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C / 8 > 256 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
     const int G = C / 8, RPB = 256 / G;
     const size_t M = (size_t)B * ((H + stride - 1) / stride) * ((W + stride - 1) / stride);
-    if (M > 0x7fffffffull || (size_t)B * H * W > 0x7fffffffull) return SMIRK_ERR_UNSUPPORTED;
+    if (M > 0x7fffffffull || (size_t)B * H * W * C * 4 >= (1ull << 31)) return SMIRK_ERR_UNSUPPORTED;     // (32-bit buffer offsets into the input)
     size_t nb = (M + RPB - 1) / RPB;
-    if (nb > 512) nb = 512;
+    if (nb > 1024) nb = 1024;                                        // four 4-wave workgroups per CU; <= 1024 fp64 partial rows for the finalisation
     *rows = (int)nb;
     smirk_prof_next(nullptr, 18.0 * (double)M * C, 4.0 * ((double)B * H * W * C + (double)M * C));
     SMIRK_LAUNCH(dwconv3x3_train_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)in, w, (float*)out, B, H, W, G, stride, part);
@@ -366,7 +383,9 @@ extern "C" int smirk_dwconv3x3_stats_split16(const void* in, const float* w, voi
 extern "C" int smirk_dwconv3x3_dgrad_split16(const void* dz, const float* w, const void* add, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     if (!dz || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
     smirk_prof_next(nullptr, 18.0 * B * H * W * C / (stride * stride), 4.0 * B * H * W * C * (1.0 + 1.0 / (stride * stride) + (add ? 1.0 : 0.0)));
-    SMIRK_LAUNCH(dw_dgrad_kernel, dim3(blocks_for((size_t)B * H * W * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)dz, w,
+    if ((size_t)B * H * W > 0x7fffffffull || C / 8 > 256) return SMIRK_ERR_UNSUPPORTED;
+    const size_t rows = ((size_t)B * H * W + (256 / (C / 8)) - 1) / (256 / (C / 8));
+    SMIRK_LAUNCH(dw_dgrad_kernel, dim3((unsigned)(rows > 16384 ? 16384 : rows)), dim3(256), 0, (hipStream_t)stream, (const float*)dz, w,
                  (const float*)add, (float*)dx, B, H, W, C / 8, stride);
     return smirk_launch_status();
 }

@@ -49,9 +49,12 @@ class _EncOps(_Ops):
             return self.depthwise(x, w9c, stride), None
         B, H, W, C = x.shape
         out = torch.empty(B, (H + stride - 1) // stride, (W + stride - 1) // stride, C, device=self.dev)
-        part = torch.empty(512 * C * 2, dtype=torch.float64, device=self.dev)
+        part = torch.empty(1024 * C * 2, dtype=torch.float64, device=self.dev)
         rows = L.C.c_int(0)
-        L.check(self.lib.smirk_dwconv3x3_stats_split16(L.ptr(x), L.ptr(w9c), L.ptr(out), B, H, W, C, stride, L.ptr(part, torch.float64), L.C.byref(rows), self.st))
+        rc = self.lib.smirk_dwconv3x3_stats_split16(L.ptr(x), L.ptr(w9c), L.ptr(out), B, H, W, C, stride, L.ptr(part, torch.float64), L.C.byref(rows), self.st)
+        if rc == L.SMIRK_ERR_UNSUPPORTED:                # inputs of 2 GiB and more: the plain kernel + the stand-alone statistics pass
+            return self.depthwise(x, w9c, stride), None
+        L.check(rc)
         return out, (part, rows.value)
 
     def depthwise_dgrad(self, dz, w9c, add, B, H, W, C, stride):
