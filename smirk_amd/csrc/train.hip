@@ -39,14 +39,20 @@ inline unsigned row_blocks(size_t M, int RPB) {                             // b
     const size_t b = (M + RPB - 1) / RPB;
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
 }
-#define RED_BLOCKS 512
+#define RED_BLOCKS 4096
 // blocks of a two-stage column reduction over a [M][C] split16 tensor.  (Round 6 tried up to 1024 blocks chosen by tensor size, eight rows in flight per thread in the
 // statistics pass and four in the apply kernels: bn_apply 3.96 -> 4.40 ms per training step, the backward sums 3.26 -> 3.69 ms, the statistics pass unchanged — the
 // extra registers cost more occupancy than the loads in flight bought — and went back to this.)
 inline unsigned red_blocks(size_t M, int C, int RPB) {
     (void)C;
     const size_t by_rows = (M + RPB - 1) / RPB;
-    return (unsigned)(by_rows > RED_BLOCKS ? RED_BLOCKS : (by_rows ? by_rows : 1));
+    size_t cap = 512;
+    if (const char* e = getenv("SMIRK_COLSUM_BLOCKS")) { const long v = atol(e); if (v >= 32 && v <= RED_BLOCKS) cap = (size_t)v; }   // sweep switch (tools/bn_sweep.py)
+    return (unsigned)(by_rows > cap ? cap : (by_rows ? by_rows : 1));
+}
+inline int colsum_rows_in_flight() {
+    if (const char* e = getenv("SMIRK_COLSUM_U")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    return 4;
 }
 inline unsigned blocks_for(size_t items, unsigned cap) {
     const size_t g = (items + 255) / 256;
@@ -71,7 +77,7 @@ __device__ __forceinline__ T ld_x(const T* p) {
     if (DEV) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <int MODE, bool DEV>
+template <int MODE, bool DEV, int U = 4>
 __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
@@ -89,10 +95,10 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
     // four rows per iteration: all their loads are issued before the first is consumed.  One row in flight per thread (8 waves per CU x 2 KB) is
     // 16 KB per CU against ~2 us of HBM latency = the 2.1-2.6 TB/s this kernel measured; the accumulation order per thread stays row-ascending.
     const size_t S = (size_t)gridDim.x * RPB;
-    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += 4 * S) {
-        float v[4][8], d[4][8];
+    for (size_t r0 = (size_t)blockIdx.x * RPB + rl; active && r0 < M; r0 += U * S) {
+        float v[U][8], d[U][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const size_t r = r0 + u * S;
             if (r < M) {
                 load_group(z + (r * G + g) * 8, v[u]);
@@ -100,7 +106,7 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (r0 + u * S >= M) break;
             if (MODE == 0) {
 #pragma unroll
@@ -127,13 +133,13 @@ __device__ __forceinline__ void colsum_partial(const float* __restrict__ z, cons
         st_x<DEV>(&part[((size_t)blockIdx.x * G * 8 + gg * 8 + (k >> 1)) * 2 + (k & 1)], a);
     }
 }
-template <int MODE>
+template <int MODE, int U = 4>
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ z, const float* __restrict__ dy, size_t M, int G,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                      double* __restrict__ part /*[blocks][C][2]*/) {
     __shared__ double red[256 * 16];
-    colsum_partial<MODE, false>(z, dy, M, G, mean, invstd, gamma, beta, relu, part, red);
+    colsum_partial<MODE, false, U>(z, dy, M, G, mean, invstd, gamma, beta, relu, part, red);
 }
 
 // stage 2: the <= 512 per-block partials of a channel are summed by 16 threads (strided, fixed order) and combined in LDS in a fixed order;
@@ -561,8 +567,8 @@ __device__ __forceinline__ half8 wgf_frag(const char* base, int off) {          
     return u.h;
 }
 
-template <int TM, int SUB, bool X1 = false, int DEPTH = 1>   // X1: hi x hi only, one MFMA per block (BASELINE config 5's 16-bit class); its own instantiations
-__global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trmap) {   // DEPTH: iterations of operand fetches in flight (register queue; see the loop)
+template <int TM, int SUB, bool X1 = false>   // X1: hi x hi only, one MFMA per block (BASELINE config 5's 16-bit class); its own instantiations
+__global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trmap) {
     constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
     constexpr int BM = TM / 32 / WAVES_M, BN = 4 / WAVES_N;                 // 32 x 32 MFMA blocks per wave: 2x2 (TM 128), 2x1 (TM 64), 1x1 (TM 32)
     constexpr int GA = TM / 8, AQ = GA / 4, BQ = 4;                         // 8-channel groups / group quads of the A (dz) and B (x, 128 columns) tiles
@@ -611,8 +617,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
     unsigned oa = (unsigned)(((unsigned long long)p0 * Gout + gco) * 32ull);
     unsigned ob = (unsigned)(((long long)p0 + (long long)(ky - a.pad) * a.W + (kx - a.pad)) * Gin + gci) * 32u;
     const unsigned a_step = (unsigned)(WG_KC * Gout * 32), b_step = (unsigned)(WG_KC * Gin * 32);
-    u32x4_t ra0[SUB][2], rb0[SUB][2], ra1[DEPTH == 2 ? SUB : 1][2], rb1[DEPTH == 2 ? SUB : 1][2];
-    auto fetch = [&](u32x4_t (*ra)[2], u32x4_t (*rb)[2]) {
+    u32x4_t ra[SUB][2], rb[SUB][2];
+    auto fetch = [&]() {
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             const bool live = fc < a.chunks_per_split && fb < a.B;
@@ -645,11 +651,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
         const int gq = wn * BN + j;
         offB[j] = (((gq * 4 + khalf * 2) * 16) + (((r4 + gq) & 3) << 2) + gl) * 16 + (q4 & 1) * 8;
     }
-    // The operands travel global -> registers -> LDS.  With one iteration of fetches in flight (round 2-5) a workgroup keeps SUB * 16 KB outstanding, two workgroups per
-    // CU 64 KB — against ~2 us of L2 / Infinity-Cache latency that is ~8 TB/s over the chip, exactly the rate the kernel measured (0.10 of the MFMA roof, the
-    // matrix pipe 30 % busy): the kernel is bound by bytes in flight, not by the matrix pipe or the LDS.  DEPTH = 2 keeps a SECOND iteration's fetches in a second
-    // register set (+32 VGPRs; 207 -> ~240 of the 256 a two-workgroup CU allows): the loads issued under iteration `it` are consumed at `it + 2`.
-    auto iteration = [&](int it, u32x4_t (*ra)[2], u32x4_t (*rb)[2]) {
+    // (Round 6 kept a SECOND iteration's fetches in flight in a second register set — 207 -> 236 VGPRs, 64 KB outstanding per workgroup instead of 32 — on the theory that
+    // the kernel is bound by bytes in flight: 4.903 -> 4.907 ms per training step, i.e. nothing.  It is not latency-bound; what limits it stays open.  Removed again.)
+    fetch();
+    for (int it = 0; it < iters; ++it) {
         const int buf = it & 1;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
             *(u32x4_t*)(Bs[buf][s] + wb_hi) = rb[s][0]; *(u32x4_t*)(Bs[buf][s] + wb_lo) = rb[s][1];
         }
         __syncthreads();                       // this stage visible; the stage written next iteration was last read two iterations ago, behind this barrier
-        if (it + DEPTH < iters) fetch(ra, rb);
+        if (it + 1 < iters) fetch();
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             half8 ah[BM], al[BM], bh[BN], bl[BN];
@@ -676,12 +681,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(WgradArgs a, int trma
                     }
                 }
         }
-    };
-    fetch(ra0, rb0);
-    if constexpr (DEPTH == 2) { if (iters > 1) fetch(ra1, rb1); }
-    for (int it = 0; it < iters; it += DEPTH) {
-        iteration(it, ra0, rb0);
-        if constexpr (DEPTH == 2) { if (it + 1 < iters) iteration(it + 1, ra1, rb1); }
     }
     float* out = a.part + (size_t)split * a.Cout * N;
 #pragma unroll
@@ -1152,8 +1151,14 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     const int G = C / 8, RPB = 256 / G;
     const unsigned nb = red_blocks(M, C, RPB);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
-    SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
-                 (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+    switch (colsum_rows_in_flight()) {
+        case 1: SMIRK_LAUNCH((colsum_stage1<0, 1>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
+                             (const float*)nullptr, (const float*)nullptr, 0, (double*)ws); break;
+        case 2: SMIRK_LAUNCH((colsum_stage1<0, 2>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
+                             (const float*)nullptr, (const float*)nullptr, 0, (double*)ws); break;
+        default: SMIRK_LAUNCH((colsum_stage1<0, 4>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
+                              (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+    }
     SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
                  save_invstd, running_mean, running_var, num_batches_tracked);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
@@ -1198,7 +1203,11 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
     const unsigned nb = red_blocks(M, C, RPB);
-    SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
+    switch (colsum_rows_in_flight()) {
+        case 1: SMIRK_LAUNCH((colsum_stage1<1, 1>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws); break;
+        case 2: SMIRK_LAUNCH((colsum_stage1<1, 2>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws); break;
+        default: SMIRK_LAUNCH((colsum_stage1<1, 4>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
+    }
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
     SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G,
@@ -1285,10 +1294,6 @@ static bool wgrad_halo_ok(int W, int Cout, int Cin, int KH, int reflect) {
 }
 // $SMIRK_WGRAD_F16: "0" = exact-fp32 MFMA kernel (wgrad_kernel), "1" / "2" = split-fp16 x3 kernel with 1 / 2 chunks per barrier (default 2);
 // "+16" (17 / 18) selects the alternative lane geometry of the LDS transpose read (diagnostic)
-static bool wgrad_depth2() {                                       // $SMIRK_WGRAD_DEPTH=1: one iteration of operand fetches in flight (rounds 2-5); default 2 (A/B switch, read per call)
-    const char* e = getenv("SMIRK_WGRAD_DEPTH");
-    return !(e && e[0] == '1');
-}
 static int g_wgrad_mode_override = -1;
 static std::atomic<unsigned long long> g_wgrad_x1_fallbacks{0};
 static int wgrad_f16_mode() {
@@ -1407,7 +1412,6 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         if (x1) {                                                            // (always two chunks per barrier: the measured default)
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 2, true>), grid, dim3(256), 0, st, a, trmap);
             else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 2, true>), grid, dim3(256), 0, st, a, trmap);
-            else if (wgrad_depth2()) SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, true, 2>), grid, dim3(256), 0, st, a, trmap);
             else SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, true>), grid, dim3(256), 0, st, a, trmap);
         } else if ((mode & 15) == 1) {
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 1>), grid, dim3(256), 0, st, a, trmap);
@@ -1416,7 +1420,6 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         } else {
             if (TM == 32) SMIRK_LAUNCH((wgrad_f16_kernel<32, 2>), grid, dim3(256), 0, st, a, trmap);
             else if (TM == 64) SMIRK_LAUNCH((wgrad_f16_kernel<64, 2>), grid, dim3(256), 0, st, a, trmap);
-            else if (wgrad_depth2()) SMIRK_LAUNCH((wgrad_f16_kernel<128, 2, false, 2>), grid, dim3(256), 0, st, a, trmap);
             else SMIRK_LAUNCH((wgrad_f16_kernel<128, 2>), grid, dim3(256), 0, st, a, trmap);
         }
     } else if (TM == 32) SMIRK_LAUNCH(wgrad_kernel<32>, grid, dim3(256), 0, st, a);

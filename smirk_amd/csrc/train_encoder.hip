@@ -39,26 +39,17 @@ __host__ __device__ inline int pad_lead(int n, int s) {
 }
 
 // dX[b,iy,ix,c] = sum_{ky,kx} dZ[b,oy,ox,c] * w[ky,kx,c]  over the outputs whose tap (ky,kx) reads (iy,ix):  oy*s - pt + ky = iy
-// Thread = (8-channel group g = tid % G, pixel lane tid / G): a thread keeps its group for the whole launch, so the group's 72 weights sit in registers and an item costs
-// two 32-bit divisions (round 5's flat 64-bit index spent three 64-bit divisions and eight weight loads per tap on every item: the kernel was VALU-bound at 1.8 TB/s).
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w /*[9][C]*/, const float* __restrict__ add,
                                                        float* __restrict__ dx, int B, int H, int W, int G, int stride) {
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const int pt = pad_lead(H, stride), pl = pad_lead(W, stride), C = G * 8;
-    const int tid = threadIdx.x, g = tid % G, rl = tid / G, RPB = 256 / G;
-    if (rl >= RPB) return;
-    float wt[9][8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const f32x4 w0 = *(const f32x4*)(w + k * C + g * 8), w1 = *(const f32x4*)(w + k * C + g * 8 + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { wt[k][q] = w0[q]; wt[k][4 + q] = w1[q]; }
-    }
-    const unsigned M = (unsigned)B * H * W, HW = (unsigned)H * W;
-    for (unsigned r = blockIdx.x * RPB + rl; r < M; r += gridDim.x * RPB) {
-        const unsigned b = r / HW, rem = r - b * HW;
-        const int iy = (int)(rem / W), ix = (int)(rem - (unsigned)iy * W);
-        const size_t i = (size_t)r * G + g;
+    const size_t total = (size_t)B * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const size_t b = t / H;
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
@@ -76,14 +67,18 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
                 const int ox = tx / stride;
                 if (ox >= Wo) continue;
                 float v[8];
-                load_group(dz + ((((size_t)b * Ho + oy) * Wo + ox) * G + g) * 8, v);
+                load_group(dz + (((b * Ho + oy) * Wo + ox) * G + g) * 8, v);
+                const float* ww = w + (ky * 3 + kx) * C + g * 8;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = fmaf(v[q], wt[ky * 3 + kx][q], acc[q]);
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(v[q], ww[q], acc[q]);
             }
         }
         store_group(dx + i * 8, acc);
     }
 }
+// (Round 6 re-indexed this kernel like dwconv3x3_train_kernel — a lane keeps its channel group, the group's 72 weights in registers, two 32-bit divisions per item —
+// and measured it SLOWER: 1.06 -> 1.42 ms per training step (1.9 -> 1.4 TB/s).  The flat index lets consecutive lanes walk consecutive 32-byte pieces of memory whatever G
+// is; the (group, lane) mapping leaves 256 mod G lanes idle and costs 72 VGPRs of occupancy.  Reverted.)
 
 // dW[ky,kx,c] = sum over output pixels of dZ[b,oy,ox,c] * X[b, oy*s-pt+ky, ox*s-pl+kx, c].  Stage 1: each block walks its share of the output rows,
 // thread = (row lane, channel group), 72 fp32 partial sums per thread (a thread sees <= a few dozen rows), combined over the row lanes in fp64.
@@ -383,9 +378,7 @@ extern "C" int smirk_dwconv3x3_stats_split16(const void* in, const float* w, voi
 extern "C" int smirk_dwconv3x3_dgrad_split16(const void* dz, const float* w, const void* add, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     if (!dz || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (stride != 1 && stride != 2)) return SMIRK_ERR_BAD_ARG;
     smirk_prof_next(nullptr, 18.0 * B * H * W * C / (stride * stride), 4.0 * B * H * W * C * (1.0 + 1.0 / (stride * stride) + (add ? 1.0 : 0.0)));
-    if ((size_t)B * H * W > 0x7fffffffull || C / 8 > 256) return SMIRK_ERR_UNSUPPORTED;
-    const size_t rows = ((size_t)B * H * W + (256 / (C / 8)) - 1) / (256 / (C / 8));
-    SMIRK_LAUNCH(dw_dgrad_kernel, dim3((unsigned)(rows > 16384 ? 16384 : rows)), dim3(256), 0, (hipStream_t)stream, (const float*)dz, w,
+    SMIRK_LAUNCH(dw_dgrad_kernel, dim3(blocks_for((size_t)B * H * W * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream, (const float*)dz, w,
                  (const float*)add, (float*)dx, B, H, W, C / 8, stride);
     return smirk_launch_status();
 }
