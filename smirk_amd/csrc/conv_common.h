@@ -46,6 +46,15 @@ __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo) {
         hi[q] = h.x; hi[q + 1] = h.y; lo[q] = l.x; lo[q + 1] = l.y;
     }
 }
+// split WITHOUT an audit: for values that are the maximum / a copy of values audited a few lines earlier (the fused 2 x 2 max-pool outputs)
+__device__ __forceinline__ void split8_noaudit(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        smirk_half2 h, l;
+        smirk_split2(v[q], v[q + 1], h, l);
+        hi[q] = h.x; hi[q + 1] = h.y; lo[q] = l.x; lo[q + 1] = l.y;
+    }
+}
 // the same split for the hot epilogues: the range audit goes into the lane's running maximum (SmirkRangeAcc, common.h), tested once per kernel
 template <typename RA>
 __device__ __forceinline__ void split8(const float* v, half8& hi, half8& lo, RA& ra) {

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv3x3_ring_kernel(Ring
                     for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
                 }
                 half8 hi, lo;
-                split8(m, hi, lo, rng);
+                split8_noaudit(m, hi, lo);                            // (the maximum of four values audited in the item loop above)
                 float* o = a.pool + (((size_t)b * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox0 >> 1) + pp) * COUT + g * 8;
                 *(half8*)o = hi;
                 *(half8*)(o + 4) = lo;

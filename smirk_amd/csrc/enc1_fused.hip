@@ -88,8 +88,11 @@ __device__ __forceinline__ void e1_split2(float a, float b, unsigned& hi, unsign
 // stages).  Left to itself hipcc's scheduler, minimising register pressure next to the 255-VGPR matrix phases, emitted each value's nine dependent
 // operations back to back through ONE temporary register: ~9 cycles per VALU instruction, 4-6 k cycles per epilogue (tools/enc1_timeline.py).
 #define E1_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <bool AUDIT>
 __device__ __forceinline__ void e1_split8(float (&y)[8], unsigned (&hi)[4], unsigned (&lo)[4], SmirkRangeAccS& rng) {
-    rng.see8(y);                                                     // split-fp16 range audit (common.h): running max, tested once per kernel
+    // split-fp16 range audit (common.h) at ONE of the three split sites, the stored output: an overflow of the conv1 intermediate turns into inf / NaN in every
+    // output channel of conv2 and is caught there; the pooled values are maxima of audited values
+    if constexpr (AUDIT) rng.see8(y);
     half2v h[4];
     float d[8];
 #pragma unroll
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                         for (int r = 0; r < 8; ++r) y[r] = inimg ? fmaxf(y[r], 0.f) : 0.f;
                         E1_FENCE();
                         unsigned hi[4], lo[4];
-                        e1_split8(y, hi, lo, rng);
+                        e1_split8<false>(y, hi, lo, rng);
                         if (own) {                                    // (a dump row for the other lanes serialises: same-address LDS writes are bank conflicts)
 #pragma unroll
                             for (int jj = 0; jj < 2; ++jj) {
@@ -443,8 +446,8 @@ __global__ __launch_bounds__(512, 2) void enc1_fused_kernel(Enc1Args a) {
                     for (int r = 0; r < 8; ++r) pz[r] = e1_max(pz[r], pw[r]);
                     E1_FENCE();
                     unsigned hi[4], lo[4], phi[4], plo[4];
-                    e1_split8(y, hi, lo, rng);
-                    e1_split8(pz, phi, plo, rng);
+                    e1_split8<true>(y, hi, lo, rng);
+                    e1_split8<false>(pz, phi, plo, rng);
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = hf * 2 + jj;

@@ -39,21 +39,18 @@ inline unsigned row_blocks(size_t M, int RPB) {                             // b
     const size_t b = (M + RPB - 1) / RPB;
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
 }
-#define RED_BLOCKS 4096
+#define RED_BLOCKS 512
 // blocks of a two-stage column reduction over a [M][C] split16 tensor.  (Round 6 tried up to 1024 blocks chosen by tensor size, eight rows in flight per thread in the
 // statistics pass and four in the apply kernels: bn_apply 3.96 -> 4.40 ms per training step, the backward sums 3.26 -> 3.69 ms, the statistics pass unchanged — the
 // extra registers cost more occupancy than the loads in flight bought — and went back to this.)
 inline unsigned red_blocks(size_t M, int C, int RPB) {
     (void)C;
     const size_t by_rows = (M + RPB - 1) / RPB;
-    size_t cap = 512;
-    if (const char* e = getenv("SMIRK_COLSUM_BLOCKS")) { const long v = atol(e); if (v >= 32 && v <= RED_BLOCKS) cap = (size_t)v; }   // sweep switch (tools/bn_sweep.py)
-    return (unsigned)(by_rows > cap ? cap : (by_rows ? by_rows : 1));
+    return (unsigned)(by_rows > RED_BLOCKS ? RED_BLOCKS : (by_rows ? by_rows : 1));
 }
-inline int colsum_rows_in_flight() {
-    if (const char* e = getenv("SMIRK_COLSUM_U")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
-    return 4;
-}
+// (Round 6 swept rows in flight per thread {1, 2, 4} x stage-1 blocks {512 ... 4096} on the step's tensor shapes, profiles/r06_bn_sweep.txt: timed ALONE the three launches
+// of a BatchNorm move their 3 (forward) / 5 (backward) passes at 4.9-5.9 TB/s on the U-Net's 100-400 MB tensors whatever U is, and 512 blocks is the best count at every size —
+// more blocks only lengthen stage 2.  These kernels are at the HBM rate the part delivers; what is left to take out of BatchNorm is passes, not kernel tuning.)
 inline unsigned blocks_for(size_t items, unsigned cap) {
     const size_t g = (items + 255) / 256;
     return (unsigned)(g > cap ? cap : (g ? g : 1));
@@ -1151,14 +1148,8 @@ extern "C" int smirk_bn_train_forward_split16(const void* z, size_t M, int C, co
     const int G = C / 8, RPB = 256 / G;
     const unsigned nb = red_blocks(M, C, RPB);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4);
-    switch (colsum_rows_in_flight()) {
-        case 1: SMIRK_LAUNCH((colsum_stage1<0, 1>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
-                             (const float*)nullptr, (const float*)nullptr, 0, (double*)ws); break;
-        case 2: SMIRK_LAUNCH((colsum_stage1<0, 2>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
-                             (const float*)nullptr, (const float*)nullptr, 0, (double*)ws); break;
-        default: SMIRK_LAUNCH((colsum_stage1<0, 4>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
-                              (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
-    }
+    SMIRK_LAUNCH(colsum_stage1<0>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)nullptr, M, G, (const float*)nullptr, (const float*)nullptr,
+                 (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     SMIRK_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, (double)M, eps, momentum, save_mean, save_var,
                  save_invstd, running_mean, running_var, num_batches_tracked);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * (residual ? 3 : 2));
@@ -1203,11 +1194,7 @@ extern "C" int smirk_bn_train_backward_split16(const void* z, const void* dy, si
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 8, RPB = 256 / G;
     const unsigned nb = red_blocks(M, C, RPB);
-    switch (colsum_rows_in_flight()) {
-        case 1: SMIRK_LAUNCH((colsum_stage1<1, 1>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws); break;
-        case 2: SMIRK_LAUNCH((colsum_stage1<1, 2>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws); break;
-        default: SMIRK_LAUNCH((colsum_stage1<1, 4>), dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
-    }
+    SMIRK_LAUNCH(colsum_stage1<1>, dim3(nb), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G, save_mean, save_invstd, gamma, beta, relu, (double*)ws);
     SMIRK_LAUNCH(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)ws, (int)nb, C, dbeta, dgamma);
     smirk_prof_next(nullptr, 0.0, (double)M * C * 4 * 3);
     SMIRK_LAUNCH(bn_backward_apply_kernel, dim3(row_blocks(M, RPB)), dim3(256), 0, st, (const float*)z, (const float*)dy, M, G,

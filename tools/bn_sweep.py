@@ -1,5 +1,8 @@
 """BatchNorm statistics / backward-sum kernels (colsum_stage1<0|1>): rows in flight per thread x stage-1 blocks, on the generator's and the backbones' tensor shapes at 64 frames.
 
+(The two sweep switches $SMIRK_COLSUM_U / $SMIRK_COLSUM_BLOCKS existed for this measurement only — commit "colsum rows-in-flight / blocks as sweep switches" — and were removed
+after it: profiles/r06_bn_sweep.txt.  Without them this tool times the shipped configuration, U = 4 and <= 512 blocks, in every row.)
+
     python tools/bn_sweep.py > gpurun_out/r06_bn_sweep.txt
 """
 import os, sys
