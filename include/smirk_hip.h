@@ -497,16 +497,6 @@ int smirk_conv_wgrad_f16x1(const void* dz, const void* x, float* dw, int B, int 
  * x1 != 0 asks for the f16x1 arithmetic where the fp16 kernels serve the call (falls back to the f32-class kernels otherwise, like the Python caller did). */
 int smirk_conv_wgrad_param(const void* dz, const void* x, float* dw_param, int B, int H, int W, int Cout, int Cin, int KH, int reflect, int layout, int cin_total,
                            int cin_off, int cin_real, int x1, void* ws, size_t ws_bytes, void* stream);
-/* The same with the split-K reductions of MANY layers deferred into ONE launch (a backward pass of the generator ends 33 weight gradients: their reductions are leaves
- * of the chain and need not sit in it).  smirk_wgrad_batch_create wraps a caller-owned device workspace (any size >= the largest single layer's
- * smirk_conv_wgrad_workspace_bytes; ~1 GiB holds half a generator backward at 64 frames); smirk_conv_wgrad_param_batched launches the GEMM kernel into a slice of it and
- * records the reduction (flushing by itself when the workspace or its 48-entry table is full); smirk_wgrad_batch_flush launches the one reduction for everything pending —
- * on the same stream, before anything reads the gradients; every dw_param must stay alive until then.  Results are bit-identical to smirk_conv_wgrad_param. */
-void* smirk_wgrad_batch_create(void* ws, size_t ws_bytes);
-void smirk_wgrad_batch_destroy(void* batch);
-int smirk_wgrad_batch_flush(void* batch, void* stream);
-int smirk_conv_wgrad_param_batched(void* batch, const void* dz, const void* x, float* dw_param, int B, int H, int W, int Cout, int Cin, int KH, int reflect, int layout,
-                                   int cin_total, int cin_off, int cin_real, int x1, void* stream);
 /* number of smirk_conv_wgrad_param calls since load that asked for x1 and were served by the f32-class kernels instead: lets the caller tell the user that a
  * step declared f16x1 (the reference: bf16 autocast, base_trainer.py / smirk_trainer.py:349-376) mixed arithmetics, instead of doing so silently */
 unsigned long long smirk_conv_wgrad_x1_fallbacks(void);

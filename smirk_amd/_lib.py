@@ -159,10 +159,6 @@ _SIGS = {
     "smirk_conv_wgrad_f16x1": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_conv_wgrad_param": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "smirk_conv_wgrad_x1_fallbacks": (C.c_ulonglong, []),
-    "smirk_wgrad_batch_create": (_p, [_p, _sz]),
-    "smirk_wgrad_batch_destroy": (None, [_p]),
-    "smirk_wgrad_batch_flush": (_i, [_p, _p]),
-    "smirk_conv_wgrad_param_batched": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "smirk_pack_conv_weights_batch_split16": (_i, [_p, _i, C.c_ulonglong, _p]),
     "smirk_pack_conv_weights_split16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "smirk_stem_conv_s2_raw_split16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

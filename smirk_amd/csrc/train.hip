@@ -16,7 +16,6 @@
 #include <stdlib.h>
 
 #include <atomic>
-#include <new>
 #include <mutex>
 #include <unordered_map>
 
@@ -1004,48 +1003,28 @@ __global__ __launch_bounds__(NW * 64) void wgrad3x3_halo_f16_kernel(WgradArgs a,
 //             sources of a decoder convolution write the two channel ranges of ONE gradient tensor)
 //   layout 2  nn.ConvTranspose2d(2, 2) parameter  dw[row][co][dydx]  of a [Cin_t][Cout_t][2][2] tensor, from the packed [row][(dydx, co)] (row = input channel)
 struct WgradLayout { int mode, T, Cin, cin_total, cin_off, cin_real; };
-__device__ __forceinline__ void wgrad_reduce_item(const float* __restrict__ part, int nsplit, size_t n, size_t i, float* __restrict__ dw, const WgradLayout& L) {
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // 8 independent chains keep 8 loads in flight; combined in a fixed order
-    int k = 0;
-    for (; k + 8 <= nsplit; k += 8)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += part[(size_t)(k + j) * n + i];
-    for (; k < nsplit; ++k) s[0] += part[(size_t)k * n + i];
-    const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    if (L.mode == 0) {
-        dw[i] = v;
-    } else if (L.mode == 1) {
-        const int N = L.T * L.Cin;
-        const size_t co = i / (size_t)N;
-        const int rem = (int)(i - co * N), t = rem / L.Cin, ci = rem - t * L.Cin;
-        if (ci < L.cin_real) dw[((size_t)co * L.cin_total + L.cin_off + ci) * L.T + t] = v;
-    } else {
-        const int N = L.Cin;                                          // = 4 * Cout_t columns (dydx, co)
-        const size_t row = i / (size_t)N;
-        const int rem = (int)(i - row * N), ct = N / 4, dydx = rem / ct, co = rem - dydx * ct;
-        dw[((size_t)row * ct + co) * 4 + dydx] = v;
-    }
-}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ dw, WgradLayout L) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) wgrad_reduce_item(part, nsplit, n, i, dw, L);
-}
-// The split-K reductions of MANY layers in one launch (round 6).  A backward pass used to end every weight gradient with its own reduction: 67 launches of ~27 us per
-// training step, each reading ~64 MB of partials at 2.4 TB/s — leaves of the backward chain that nevertheless sat IN the chain of the stream.  The GEMM kernels now write
-// their partials into slices of one workspace and append a job; ONE launch at the end of the pass (or when the workspace / the table is full) reduces them all.  The job
-// table travels BY VALUE in the kernel arguments (48 jobs x 56 bytes: no host-to-device copy, nothing to keep alive); an item finds its job by binary search.  Per
-// output the arithmetic is wgrad_reduce_item, i.e. bit-identical to the per-layer launches.
-#define WG_BATCH_MAX 48
-struct WgradJob { const float* part; float* dw; unsigned long long start; unsigned n; int nsplit; WgradLayout L; };
-struct WgradJobTable { int njobs, pad; WgradJob j[WG_BATCH_MAX]; };
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WgradJobTable t, unsigned long long total) {
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = t.njobs - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (t.j[mid].start <= i) lo = mid; else hi = mid - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // 8 independent chains keep 8 loads in flight; combined in a fixed order
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += part[(size_t)(k + j) * n + i];
+        for (; k < nsplit; ++k) s[0] += part[(size_t)k * n + i];
+        const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        if (L.mode == 0) {
+            dw[i] = v;
+        } else if (L.mode == 1) {
+            const int N = L.T * L.Cin;
+            const size_t co = i / (size_t)N;
+            const int rem = (int)(i - co * N), t = rem / L.Cin, ci = rem - t * L.Cin;
+            if (ci < L.cin_real) dw[((size_t)co * L.cin_total + L.cin_off + ci) * L.T + t] = v;
+        } else {
+            const int N = L.Cin;                                          // = 4 * Cout_t columns (dydx, co)
+            const size_t row = i / (size_t)N;
+            const int rem = (int)(i - row * N), ct = N / 4, dydx = rem / ct, co = rem - dydx * ct;
+            dw[((size_t)row * ct + co) * 4 + dydx] = v;
         }
-        const WgradJob& J = t.j[lo];
-        wgrad_reduce_item(J.part, J.nsplit, (size_t)J.n, (size_t)(i - J.start), J.dw, J.L);
     }
 }
 
@@ -1333,20 +1312,8 @@ extern "C" size_t smirk_conv_wgrad_workspace_bytes(int B, int H, int W, int Cout
     return (size_t)wgrad_nsplit(npix, Cout, KH * KH * Cin) * Cout * KH * KH * Cin * 4;
 }
 /* dW[Cout][(ky,kx,ci)] (fp32, the packed forward layout) = sum over pixels of dz[p][co] * x[p + tap][ci];  KH in {1, 3}, pad = (KH-1)/2 */
-struct SmirkWgradBatch {                                            // host-side accumulator of deferred split-K reductions (smirk_wgrad_batch_*)
-    char* ws; size_t ws_bytes, used;
-    WgradJobTable t; unsigned long long total;
-};
-static int wgrad_batch_flush(SmirkWgradBatch* b, hipStream_t st) {
-    if (b->t.njobs > 0) {
-        SMIRK_LAUNCH(wgrad_reduce_batch_kernel, dim3(blocks_for((size_t)b->total, 8192)), dim3(256), 0, st, b->t, b->total);
-        b->t.njobs = 0; b->total = 0;
-    }
-    b->used = 0;                                                      // stream order: the reduction above reads the slices before any later GEMM kernel overwrites them
-    return smirk_launch_status();
-}
 static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
-                           void* stream, int x1, WgradLayout L = WgradLayout{0, 0, 0, 0, 0, 0}, SmirkWgradBatch* batch = nullptr);
+                           void* stream, int x1, WgradLayout L = WgradLayout{0, 0, 0, 0, 0, 0});
 extern "C" int smirk_conv_wgrad_f32(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
                                     void* stream) {
     return conv_wgrad_impl(dz, x, dw, B, H, W, Cout, Cin, KH, reflect, ws, ws_bytes, stream, 0);
@@ -1381,28 +1348,7 @@ extern "C" int smirk_conv_wgrad_param(const void* dz, const void* x, float* dw_p
  * $SMIRK_WGRAD_F16=0) since the library was loaded: the Python wrapper warns once when this moves, so a step never mixes arithmetics silently */
 extern "C" unsigned long long smirk_conv_wgrad_x1_fallbacks(void) { return g_wgrad_x1_fallbacks.load(std::memory_order_relaxed); }
 static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int H, int W, int Cout, int Cin, int KH, int reflect, void* ws, size_t ws_bytes,
-                           void* stream, int x1, WgradLayout L, SmirkWgradBatch* batch) {
-    if (batch) {                                                      // deferred reduction: the partials go into a slice of the batch's workspace
-        const size_t need = smirk_align_up(smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH), 256);
-        if (need > batch->ws_bytes) return SMIRK_ERR_WORKSPACE;
-        if (batch->used + need > batch->ws_bytes || batch->t.njobs == WG_BATCH_MAX) {
-            const int rc = wgrad_batch_flush(batch, (hipStream_t)stream);
-            if (rc != SMIRK_OK) return rc;
-        }
-        ws = batch->ws + batch->used;
-        ws_bytes = need;
-    }
-    auto finish = [&](int nsplit, size_t n, hipStream_t st_) -> int {  // per-layer reduction, or a job for the batch's one launch
-        if (!batch) {
-            SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, st_, (const float*)ws, nsplit, n, dw, L);
-            return smirk_launch_status();
-        }
-        WgradJob& J = batch->t.j[batch->t.njobs++];
-        J.part = (const float*)ws; J.dw = dw; J.start = batch->total; J.n = (unsigned)n; J.nsplit = nsplit; J.L = L;
-        batch->total += n;
-        batch->used += smirk_align_up(smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH), 256);
-        return smirk_launch_status();
-    };
+                           void* stream, int x1, WgradLayout L) {
     if (!dz || !x || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || Cout % 8 || Cin % 8 || Cout <= 0 || Cin <= 0 || (KH != 1 && KH != 3)) return SMIRK_ERR_BAD_ARG;
     if (ws_bytes < smirk_conv_wgrad_workspace_bytes(B, H, W, Cout, Cin, KH)) return SMIRK_ERR_WORKSPACE;
     const long long npix = (long long)B * H * W, chunks = (npix + WG_KC - 1) / WG_KC;
@@ -1432,7 +1378,9 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
         else if (Cout == 64 && Cin == 32) SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 32>), dim3(nsplit), dim3(256), 0, hs, h);
         else if (Cout == 32 && Cin == 64) SMIRK_LAUNCH((wgrad3x3_halo_kernel<32, 64>), dim3(nsplit), dim3(256), 0, hs, h);
         else SMIRK_LAUNCH((wgrad3x3_halo_kernel<64, 64>), dim3(nsplit), dim3(256), 0, hs, h);
-        return finish(nsplit, (size_t)Cout * N, hs);
+        const size_t nh = (size_t)Cout * N;
+        SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(nh, 4096)), dim3(256), 0, hs, (const float*)ws, nsplit, nh, dw, L);
+        return smirk_launch_status();
     }
     WgradArgs a;
     a.dz = (const float*)dz; a.x = (const float*)x; a.part = (float*)ws;
@@ -1464,40 +1412,7 @@ static int conv_wgrad_impl(const void* dz, const void* x, float* dw, int B, int 
     } else if (TM == 32) SMIRK_LAUNCH(wgrad_kernel<32>, grid, dim3(256), 0, st, a);
     else if (TM == 64) SMIRK_LAUNCH(wgrad_kernel<64>, grid, dim3(256), 0, st, a);
     else SMIRK_LAUNCH(wgrad_kernel<128>, grid, dim3(256), 0, st, a);
-    return finish(nsplit, (size_t)Cout * KH * KH * Cin, st);
-}
-
-/* Deferred split-K reductions: smirk_wgrad_batch_create(ws, bytes) wraps a caller-owned device workspace; smirk_conv_wgrad_param_batched is smirk_conv_wgrad_param with
- * the per-layer reduction launch replaced by an entry in the batch (it flushes by itself when the workspace or the 48-job table is full); smirk_wgrad_batch_flush launches
- * the ONE reduction for everything pending — call it on the same stream before anything reads the gradients.  dw_param tensors must stay alive until then. */
-extern "C" void* smirk_wgrad_batch_create(void* ws, size_t ws_bytes) {
-    if (!ws || ws_bytes < 256) return nullptr;
-    SmirkWgradBatch* b = new (std::nothrow) SmirkWgradBatch();
-    if (!b) return nullptr;
-    b->ws = (char*)ws; b->ws_bytes = ws_bytes; b->used = 0; b->t.njobs = 0; b->t.pad = 0; b->total = 0;
-    return b;
-}
-extern "C" void smirk_wgrad_batch_destroy(void* batch) { delete (SmirkWgradBatch*)batch; }
-extern "C" int smirk_wgrad_batch_flush(void* batch, void* stream) {
-    if (!batch) return SMIRK_ERR_BAD_ARG;
-    return wgrad_batch_flush((SmirkWgradBatch*)batch, (hipStream_t)stream);
-}
-extern "C" int smirk_conv_wgrad_param_batched(void* batch, const void* dz, const void* x, float* dw_param, int B, int H, int W, int Cout, int Cin, int KH, int reflect,
-                                              int layout, int cin_total, int cin_off, int cin_real, int x1, void* stream) {
-    if (!batch) return SMIRK_ERR_BAD_ARG;
-    if (layout == 1) {
-        if (cin_real <= 0 || cin_real > Cin || cin_off < 0 || cin_off + cin_real > cin_total) return SMIRK_ERR_BAD_ARG;
-    } else if (layout == 2) {
-        if (KH != 1 || Cin % 4) return SMIRK_ERR_BAD_ARG;
-    } else if (layout != 0) {
-        return SMIRK_ERR_BAD_ARG;
-    }
-    SmirkWgradBatch* b = (SmirkWgradBatch*)batch;
-    const WgradLayout L{layout, KH * KH, Cin, cin_total, cin_off, cin_real};
-    int rc = x1 ? conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, b->ws, b->ws_bytes, stream, 1, L, b) : SMIRK_ERR_UNSUPPORTED;
-    if (rc == SMIRK_ERR_UNSUPPORTED) {
-        if (x1) g_wgrad_x1_fallbacks.fetch_add(1, std::memory_order_relaxed);
-        rc = conv_wgrad_impl(dz, x, dw_param, B, H, W, Cout, Cin, KH, reflect, b->ws, b->ws_bytes, stream, 0, L, b);
-    }
-    return rc;
+    const size_t n = (size_t)Cout * KH * KH * Cin;
+    SMIRK_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n, 4096)), dim3(256), 0, st, (const float*)ws, nsplit, n, dw, L);
+    return smirk_launch_status();
 }

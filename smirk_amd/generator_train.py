@@ -76,7 +76,6 @@ class _Ops:
         self.rm_saved = {}                                # eval-mode BatchNorm: id(bn) -> running_mean as the forward saw it
         self.red_ws = torch.empty(self.lib.smirk_train_reduce_workspace_bytes(1024), dtype=torch.uint8, device=device)
         self.wg_ws = None
-        self.wbatch, self.wb_keep, self.wb_ws = None, None, None
 
     def conv_stats(self, x0, x1, w, B, H, W, cout, k=3, reflect=False):
         """the raw convolution whose BatchNorm follows: -> (z, (partials, rows) or None).  The kernel leaves per-tile partial sums (sum z, sum z^2) of its output
@@ -202,52 +201,15 @@ class _Ops:
         L.check(rc)
         return dw
 
-    WGRAD_BATCH_BYTES = 1 << 30        # workspace of the deferred split-K reductions: ~half a generator backward's partials at 64 frames (the batch flushes by itself)
-
-    def wgrad_batch_begin(self):
-        """Defer the split-K reductions of the weight gradients that follow (wgrad_param) into one launch per ~1 GiB of partials: they are leaves of the backward chain
-        (smirk_wgrad_batch_*, include/smirk_hip.h).  wgrad_batch_end() must run before the gradients are handed to autograd."""
-        import os
-        if os.environ.get("SMIRK_WGRAD_UNBATCHED"):                  # A/B switch for tests: one reduction launch per layer, as rounds 2-5
-            return
-        self.wb_ws = torch.empty(self.WGRAD_BATCH_BYTES, dtype=torch.uint8, device=self.dev)
-        self.wbatch = self.lib.smirk_wgrad_batch_create(L.ptr(self.wb_ws, torch.uint8), self.wb_ws.numel())
-        if not self.wbatch:
-            raise L.SmirkHipError("smirk_wgrad_batch_create failed")
-        self.wb_keep = []                                            # gradient tensors and operands the pending jobs point at
-
-    def __del__(self):                                               # a backward that raised half-way: do not leak the host-side batch object
-        if getattr(self, "wbatch", None):
-            try:
-                self.lib.smirk_wgrad_batch_destroy(self.wbatch)
-            except Exception:                                        # noqa: BLE001 — interpreter shutdown
-                pass
-            self.wbatch = None
-
-    def wgrad_batch_end(self):
-        if getattr(self, "wbatch", None):
-            try:
-                L.check(self.lib.smirk_wgrad_batch_flush(self.wbatch, self.st))
-            finally:
-                self.lib.smirk_wgrad_batch_destroy(self.wbatch)
-                self.wbatch, self.wb_keep = None, None
-
     def wgrad_param(self, dz, x, B, H, W, cout, cin, k, out, layout=1, cin_off=0, cin_real=None, reflect=False):
         """weight gradient summed straight into `out`, a tensor in the PARAMETER's layout (smirk_conv_wgrad_param): nn.Conv2d weight [cout][cin_total][k][k],
         channel range [cin_off, cin_off + cin_real) (layout 1) or nn.ConvTranspose2d(2, 2) weight [cout][cin / 4][2][2] (layout 2) — no permute-copy, no torch.cat"""
+        need = self.lib.smirk_conv_wgrad_workspace_bytes(B, H, W, cout, cin, k)
+        if self.wg_ws is None or self.wg_ws.numel() < need:
+            self.wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         P = L.ptr
         cin_total = out.shape[1] if layout == 1 else 0
         before = self.lib.smirk_conv_wgrad_x1_fallbacks() if self.x1 else 0
-        need = self.lib.smirk_conv_wgrad_workspace_bytes(B, H, W, cout, cin, k)
-        if getattr(self, "wbatch", None) and need + 256 <= self.WGRAD_BATCH_BYTES:
-            L.check(self.lib.smirk_conv_wgrad_param_batched(self.wbatch, P(dz), P(x), P(out), B, H, W, cout, cin, k, int(reflect), layout, cin_total, cin_off,
-                                                            cin if cin_real is None else cin_real, int(self.x1), self.st))
-            self.wb_keep.append((dz, x, out))
-            if self.x1 and self.lib.smirk_conv_wgrad_x1_fallbacks() != before:
-                _warn_x1_fallback(B, H, W, cout, cin, k)
-            return out
-        if self.wg_ws is None or self.wg_ws.numel() < need:
-            self.wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         L.check(self.lib.smirk_conv_wgrad_param(P(dz), P(x), P(out), B, H, W, cout, cin, k, int(reflect), layout, cin_total, cin_off,
                                                 cin if cin_real is None else cin_real, int(self.x1), P(self.wg_ws, torch.uint8), self.wg_ws.numel(), self.st))
         if self.x1 and self.lib.smirk_conv_wgrad_x1_fallbacks() != before:
@@ -469,7 +431,6 @@ class GeneratorTrainFunction(torch.autograd.Function):
                                   "smirk_trainer.py:108-113 does, or call .train())")
         need = lambda p: id(p) in wanted
         want_dx = bool(ctx.needs_input_grad[1])
-        ops.wgrad_batch_begin()                                            # the split-K reductions of the ~33 weight gradients below: one launch per GiB of partials
         gy = L.as_f32c(gy)
         # ---- final 1x1 conv + sigmoid ------------------------------------------------------------------------------------------------------
         dd = torch.empty_like(d1)
@@ -559,7 +520,6 @@ class GeneratorTrainFunction(torch.autograd.Function):
                 L.check(lib.smirk_maxpool2x2_backward_split16(L.ptr(t), L.ptr(g), L.ptr(skip_grad.get(level), allow_none=True), L.ptr(gx), B, h, w, c, st))
                 g = gx
             i -= 1
-        ops.wgrad_batch_end()                                              # (before autograd sees a gradient)
         dx = split16_to_float(g)[..., :Cx].permute(0, 3, 1, 2).contiguous() if (want_dx and g is not None) else None
         ctx.tape = ctx.final = None
         out = [None, dx]

@@ -203,36 +203,6 @@ def test_one_launch_weight_packing_plan_equals_per_weight_packing():
     assert same(step(m2), first)
 
 
-@pytest.mark.parametrize("arith", ["f16x3", "f16x1"])
-@pytest.mark.parametrize("B,HW", [(2, 64), (3, 96)])
-def test_batched_weight_gradient_reductions_equal_the_per_layer_launches_bit_for_bit(B, HW, arith, monkeypatch):
-    """round 6: the split-K reductions of the generator's ~33 weight gradients are deferred into one launch per GiB of partials (smirk_wgrad_batch_*: the job table
-    travels in the kernel arguments, every output is summed by the same code in the same order).  Every parameter gradient — Conv2d, the two-source decoder
-    convolutions (two jobs into one tensor), ConvTranspose2d — and the input gradient are bit-identical to the per-layer reductions ($SMIRK_WGRAD_UNBATCHED)."""
-    sd = G.synth_state_dict()
-    m = _module(sd)
-    m.train_arith = arith
-    g = torch.Generator().manual_seed(31 + B)
-    x = torch.rand(B, 6, HW, HW, generator=g).cuda()
-    wgt = torch.randn(B, 3, HW, HW, generator=g).cuda()
-
-    def step():
-        for p in m.parameters():
-            p.grad = None
-        m.load_state_dict(sd)
-        xx = x.clone().requires_grad_(True)
-        (m(xx) * wgt).sum().backward()
-        return [xx.grad.clone()] + [p.grad.clone() for p in m.parameters()]
-
-    batched = step()
-    monkeypatch.setenv("SMIRK_WGRAD_UNBATCHED", "1")
-    plain = step()
-    monkeypatch.delenv("SMIRK_WGRAD_UNBATCHED")
-    again = step()
-    assert all(torch.isfinite(t).all() for t in batched)
-    assert all(torch.equal(a, b) for a, b in zip(batched, plain)) and all(torch.equal(a, b) for a, b in zip(batched, again))
-
-
 def test_stale_tape_after_weight_update_and_another_forward_raises_like_autograd():
     """the plan-owned data-gradient weight images are re-packed in place by every forward.  forward A -> in-place weight update ->
     forward B -> backward A would silently back-propagate through B's weights; torch autograd raises a version-counter error there, and so does this path.
