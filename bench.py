@@ -787,7 +787,10 @@ def run_also(args):
     out, t_all = {}, time.perf_counter()
     for name, argv, steps, warmup, cpu_faces in ALSO_SPECS:
         t_entry = time.perf_counter()
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off",
+        # counter traffic of the child's dominant kernel: from the committed table of the same kernel sources (profiles/pmc_traffic_<workload>.json, written by a
+        # `--traffic measure` run of the same command line; withheld when its source sha differs) — two rocprofv3 passes per child would triple the run
+        # (the 128-frame shard's launches are not the 1024-frame table's launches: no traffic for that entry)
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(steps), "--warmup", str(warmup), "--traffic", "off" if "--global-batch" in argv else "file",
                                                                     "--cpu-faces", str(cpu_faces if args.cpu_faces > 0 else 0), "--cpu-passes", "3", "--no-also",
                                                                     "--flame-basis", args.flame_basis]
         try:
@@ -800,8 +803,8 @@ def run_also(args):
             e = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
                  "frames_per_step": j["config"]["frames_per_gpu_per_step"], "dtype": j["dtype"], "command": "python bench.py " + " ".join(cmd[2:]),
                  "host_enqueue_ms_one_step_idle_queue": j.get("host_enqueue_ms_one_step_idle_queue"),
-                 "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_pass", "avg_launch_ms",
-                                                       "profiled_kernel_ms_per_pass")},
+                 "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches_per_pass",
+                                                       "avg_launch_ms", "profiled_kernel_ms_per_pass")},
                  "launches_per_step": roof.get("launches_total_per_pass"),
                  "cpu_baseline": j.get("cpu_baseline") or ALSO_CPU_SAME_AS.get(name)}
             for k in ("critical_path_us", "launches_on_critical_path"):
