@@ -713,7 +713,11 @@ def roofline_from_records(recs, workload, traffic_table, traffic_source, dt_pass
     traffic = None
     if traffic_table:
         key = dom.split("[")[0]                                   # the profiler appends a "[tile,waves,stages]" tag to some names
-        t = traffic_table.get(dom) or traffic_table.get(key) or traffic_table.get(key.replace(", ", ","))
+        k2 = key.replace(", ", ",")
+        t = traffic_table.get(dom) or traffic_table.get(key) or traffic_table.get(k2)
+        if t is None and k2.endswith(">"):                        # rocprofv3 spells defaulted template arguments out (wgrad_f16_kernel<128,2> is <128,2,false> there)
+            for extra in (",false>", ",false,false>", ",0>"):
+                t = t or traffic_table.get(k2[:-1] + extra)
         traffic = (t["bytes_per_launch"] if isinstance(t, dict) else t) if t is not None else None
     # a GEMM-shaped launch whose arithmetic intensity sits below the ridge point (MFMA peak of its arithmetic mode / HBM peak) is priced against HBM:
     # the encoder's 1x1 convolutions over 16-72 channels move 4 bytes per 8-36 flop
@@ -928,7 +932,10 @@ def main():
             try:
                 j = json.load(open(os.path.join(REPO, "profiles", f"pmc_traffic_{args.workload}.json")))
                 if j.get("kernel_sources_sha") == kernel_sources_sha() and j.get("workload", "full") == args.workload:
-                    table, src = j["kernels"], src + f"; profiles/pmc_traffic_{args.workload}.json (same kernel sources, sha " + j["kernel_sources_sha"] + ")"
+                    table = j["kernels"]
+                    src = ((src + "; ") if src != "not collected" else "") + (f"profiles/pmc_traffic_{args.workload}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a "
+                           f"`bench.py --workload {args.workload} --traffic measure` run on the same kernel sources (sha " + j["kernel_sources_sha"] +
+                           "); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch")
                 else:
                     src += f"; profiles/pmc_traffic_{args.workload}.json was measured on different kernel sources / workload -> traffic withheld (null)"
             except Exception:               # noqa: BLE001
